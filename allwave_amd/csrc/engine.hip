@@ -1,0 +1,465 @@
+// engine.hip -- host side of liballwave_hip.so: the C ABI of include/allwave_hip.h.
+//
+// Owns all device state for one GPU (what the reference keeps in per-thread cached WFA2
+// aligners, /root/reference/src/alignment.rs:11-22,210-221): sequence copies, per-workgroup
+// wavefront arenas sized for 288 GB of HBM, result/CIGAR arenas, one stream.  There is no CPU
+// fallback: without a HIP device every entry point fails with AWV_ERR_NO_DEVICE.
+#include "allwave_hip.h"
+#include "biwfa_device.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return fail(_e == hipErrorOutOfMemory ? AWV_ERR_OOM : AWV_ERR_HIP,                       \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));                          \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+  int reserve(size_t n) {
+    if (n <= cap) return AWV_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e != hipSuccess) {
+      want = n;
+      e = hipMalloc((void**)&p, want * sizeof(T));
+    }
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(AWV_ERR_OOM, std::string("hipMalloc ") + std::to_string(want * sizeof(T)) + " bytes: " + hipGetErrorString(e));
+    }
+    cap = want;
+    return AWV_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  size_t bytes() const { return cap * sizeof(T); }
+};
+
+struct SeqSet {
+  int32_t n = 0;
+  std::vector<uint64_t> off;   // padded device layout
+  std::vector<int32_t> len;
+  DevBuf<uint8_t> d_seq[4];
+  DevBuf<uint64_t> d_off;
+  DevBuf<int32_t> d_len;
+  size_t total = 0;
+  void release() {
+    for (auto& b : d_seq) b.release();
+    d_off.release();
+    d_len.release();
+    n = 0;
+  }
+};
+
+// reverse_complement of /root/reference/src/alignment.rs:178-190
+inline uint8_t rc_base(uint8_t b) {
+  switch (b) {
+    case 'A': case 'a': return 'T';
+    case 'T': case 't': return 'A';
+    case 'C': case 'c': return 'G';
+    case 'G': case 'g': return 'C';
+    default: return 'N';
+  }
+}
+
+}  // namespace
+
+struct awv_engine {
+  awv_engine_config cfg{};
+  int device = 0;
+  int num_cus = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  SeqSet seqs;
+  // scratch arenas (per persistent workgroup)
+  DevBuf<int32_t> ring_mem, hist_mem;
+  DevBuf<uint32_t> ev_mem;
+  // per-launch buffers
+  DevBuf<int32_t> d_pair_q, d_pair_t, d_pair_rc;
+  DevBuf<uint64_t> d_cigar_off;
+  DevBuf<awv::DevResult> d_results;
+  DevBuf<uint8_t> d_cigar;
+  DevBuf<unsigned long long> d_counters;  // [0] work cursor, [1..] stats
+  std::vector<uint8_t> h_cigar;
+  awv_stats stats{};
+};
+
+namespace {
+
+int upload_seqset(awv_engine* e, SeqSet& s, int32_t n, const uint8_t* bytes, const uint64_t* offsets) {
+  if (n < 0 || (n > 0 && (!bytes || !offsets))) return fail(AWV_ERR_ARG, "set_sequences: null input");
+  s.n = n;
+  s.off.assign((size_t)n + 1, 0);
+  s.len.assign((size_t)n, 0);
+  uint64_t run = 0;
+  for (int i = 0; i < n; ++i) {
+    if (offsets[i + 1] < offsets[i]) return fail(AWV_ERR_ARG, "set_sequences: offsets not monotone");
+    const uint64_t l = offsets[i + 1] - offsets[i];
+    if (l > (uint64_t)(INT32_MAX / 4)) return fail(AWV_ERR_ARG, "set_sequences: sequence too long");
+    s.off[i] = run;
+    s.len[i] = (int32_t)l;
+    run += l + 8;  // extend reads 8 bytes at a time: keep over-reads inside the allocation
+  }
+  s.off[n] = run;
+  s.total = run + 64;
+  std::vector<uint8_t> h[4];
+  for (auto& v : h) v.assign(s.total, 0);
+  for (int i = 0; i < n; ++i) {
+    const uint8_t* src = bytes + offsets[i];
+    const size_t l = (size_t)s.len[i];
+    uint8_t* f = h[0].data() + s.off[i];
+    uint8_t* r = h[1].data() + s.off[i];
+    uint8_t* c = h[2].data() + s.off[i];
+    uint8_t* cr = h[3].data() + s.off[i];
+    for (size_t j = 0; j < l; ++j) {
+      const uint8_t b = src[j];
+      f[j] = b;
+      r[l - 1 - j] = b;
+      const uint8_t cb = rc_base(b);
+      c[l - 1 - j] = cb;  // reverse complement
+      cr[j] = cb;         // its reversal
+    }
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  for (int v = 0; v < 4; ++v) {
+    if (int rc = s.d_seq[v].reserve(s.total)) return rc;
+    HIP_TRY(hipMemcpyAsync(s.d_seq[v].p, h[v].data(), s.total, hipMemcpyHostToDevice, e->stream));
+  }
+  if (int rc = s.d_off.reserve((size_t)n + 1)) return rc;
+  if (int rc = s.d_len.reserve((size_t)std::max(n, 1))) return rc;
+  HIP_TRY(hipMemcpyAsync(s.d_off.p, s.off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  if (n > 0) HIP_TRY(hipMemcpyAsync(s.d_len.p, s.len.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return AWV_OK;
+}
+
+int check_penalties(const awv_penalties* p, awv::DevPenalties& d) {
+  if (!p) return fail(AWV_ERR_ARG, "penalties: null");
+  if (p->match != 0) return fail(AWV_ERR_PENALTIES, "match score must be 0 (WFA2 penalty transformation is out of scope)");
+  if (p->mismatch <= 0 || p->gap_open1 < 0 || p->gap_ext1 <= 0) return fail(AWV_ERR_PENALTIES, "need x > 0, o >= 0, e > 0");
+  if (p->two_piece && (p->gap_open2 < 0 || p->gap_ext2 <= 0)) return fail(AWV_ERR_PENALTIES, "need o2 >= 0, e2 > 0");
+  d.x = p->mismatch;
+  d.o1 = p->gap_open1;
+  d.e1 = p->gap_ext1;
+  d.two_piece = p->two_piece ? 1 : 0;
+  d.o2 = d.two_piece ? p->gap_open2 : p->gap_open1;
+  d.e2 = d.two_piece ? p->gap_ext2 : p->gap_ext1;
+  int scope = std::max(d.x, d.o1 + d.e1);
+  if (d.two_piece) scope = std::max(scope, d.o2 + d.e2);
+  d.scope = scope + 1;
+  if (d.scope + 2 > awv::MAX_RING) return fail(AWV_ERR_PENALTIES, "penalties too large: max(x, o+e) must be < 126");
+  return AWV_OK;
+}
+
+// worst-case penalty of an end-to-end alignment of two sequences of length <= n
+long long worst_case_penalty(const awv::DevPenalties& d, long long n) {
+  auto gap = [&](long long l) {
+    long long g = d.o1 + l * d.e1;
+    if (d.two_piece) g = std::min(g, (long long)d.o2 + l * d.e2);
+    return g;
+  };
+  return std::min(2 * gap(n), n * (long long)d.x + gap(n));
+}
+
+int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pair* pairs, int64_t npairs,
+               awv_result* out, awv_sink sink, void* user) {
+  using namespace awv;
+  if (npairs < 0 || (npairs > 0 && !pairs)) return fail(AWV_ERR_ARG, "align_pairs: null pairs");
+  DevPenalties dp{};
+  if (int rc = check_penalties(pen, dp)) return rc;
+  HIP_TRY(hipSetDevice(e->device));
+  e->stats = awv_stats{};
+  if (npairs == 0) return AWV_OK;
+  for (int64_t i = 0; i < npairs; ++i) {
+    if (pairs[i].q_idx < 0 || pairs[i].q_idx >= s.n || pairs[i].t_idx < 0 || pairs[i].t_idx >= s.n)
+      return fail(AWV_ERR_ARG, "align_pairs: sequence index out of range");
+  }
+  int ring = 4;
+  while (ring < dp.scope + 2) ring *= 2;
+  const int nslots_cfg = e->cfg.workgroups > 0 ? e->cfg.workgroups : 2 * e->num_cus;
+  const int64_t max_batch = e->cfg.max_batch_pairs > 0 ? e->cfg.max_batch_pairs : (int64_t)1 << 20;
+  const uint64_t max_arena = e->cfg.max_arena_bytes > 0 ? (uint64_t)e->cfg.max_arena_bytes : (uint64_t)8 << 30;
+  // base-case capacities: score_remaining <= 250 or both lengths <= 100
+  const long long sb = std::max<long long>(FALLBACK_MIN_SCORE, worst_case_penalty(dp, FALLBACK_MIN_LENGTH));
+  if (sb > 4000) return fail(AWV_ERR_PENALTIES, "penalties too large for the base-case history");
+  const int sb_cap = (int)sb;
+  const int wb_cap = ((2 * sb_cap + 9) + 63) & ~63;
+  const size_t dyn_lds = (size_t)(sb_cap + 1) * NCOMP * sizeof(RowMeta);
+
+  std::vector<int32_t> hq, ht, hrc;
+  std::vector<uint64_t> hoff;
+  std::vector<awv_result> hres;
+  int64_t first = 0;
+  double kernel_ms = 0, h2d_ms = 0, d2h_ms = 0;
+  unsigned long long stat_tot[STAT_N] = {0};
+  uint64_t launches = 0;
+  while (first < npairs) {
+    // ---- carve a batch
+    int64_t n = 0;
+    uint64_t arena = 0;
+    int maxsum = 0;
+    hq.clear(); ht.clear(); hrc.clear(); hoff.clear();
+    while (first + n < npairs && n < max_batch) {
+      const awv_pair& p = pairs[first + n];
+      const int ql = s.len[p.q_idx], tl = s.len[p.t_idx];
+      const uint64_t need = ((uint64_t)ql + (uint64_t)tl + 7) & ~(uint64_t)7;
+      if (n > 0 && arena + need > max_arena) break;
+      hq.push_back(p.q_idx);
+      ht.push_back(p.t_idx);
+      hrc.push_back(p.q_revcomp ? 1 : 0);
+      hoff.push_back(arena);
+      arena += need;
+      maxsum = std::max(maxsum, ql + tl);
+      ++n;
+    }
+    const int wcap = ((maxsum + 9 + 64) + 63) & ~63;
+    const int nslots = (int)std::min<int64_t>(nslots_cfg, n);
+    const size_t ring_stride = (size_t)2 * NCOMP * ring * wcap;
+    const size_t hist_stride = (size_t)(sb_cap + 1) * NCOMP * wb_cap;
+    const size_t ev_stride = (size_t)wcap;
+    if (int rc = e->ring_mem.reserve(ring_stride * nslots)) return rc;
+    if (int rc = e->hist_mem.reserve(hist_stride * nslots)) return rc;
+    if (int rc = e->ev_mem.reserve(ev_stride * nslots)) return rc;
+    if (int rc = e->d_pair_q.reserve((size_t)n)) return rc;
+    if (int rc = e->d_pair_t.reserve((size_t)n)) return rc;
+    if (int rc = e->d_pair_rc.reserve((size_t)n)) return rc;
+    if (int rc = e->d_cigar_off.reserve((size_t)n)) return rc;
+    if (int rc = e->d_results.reserve((size_t)n)) return rc;
+    if (int rc = e->d_cigar.reserve((size_t)arena + 64)) return rc;
+    if (int rc = e->d_counters.reserve(1 + STAT_N)) return rc;
+    // ---- H2D
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_pair_q.p, hq.data(), (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_pair_t.p, ht.data(), (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_pair_rc.p, hrc.data(), (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_cigar_off.p, hoff.data(), (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_counters.p, 0, (1 + STAT_N) * sizeof(unsigned long long), e->stream));
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    h2d_ms += ms;
+    // ---- launch
+    KParams kp{};
+    for (int v = 0; v < 4; ++v) kp.seq[v] = s.d_seq[v].p;
+    kp.seq_off = s.d_off.p;
+    kp.seq_len = s.d_len.p;
+    kp.pair_q = e->d_pair_q.p;
+    kp.pair_t = e->d_pair_t.p;
+    kp.pair_rc = e->d_pair_rc.p;
+    kp.npairs = n;
+    kp.pen = dp;
+    kp.ring = ring;
+    kp.wcap = wcap;
+    kp.ring_mem = e->ring_mem.p;
+    kp.ring_slot_stride = ring_stride;
+    kp.sb_cap = sb_cap;
+    kp.wb_cap = wb_cap;
+    kp.hist_mem = e->hist_mem.p;
+    kp.hist_slot_stride = hist_stride;
+    kp.ev_mem = e->ev_mem.p;
+    kp.ev_slot_stride = ev_stride;
+    kp.cigar = e->d_cigar.p;
+    kp.cigar_off = e->d_cigar_off.p;
+    kp.results = e->d_results.p;
+    kp.work_counter = e->d_counters.p;
+    kp.stats = e->d_counters.p + 1;
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    if (dp.two_piece) {
+      HIP_TRY(hipFuncSetAttribute((const void*)biwfa_align_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+      hipLaunchKernelGGL(biwfa_align_kernel<true>, dim3(nslots), dim3(WG), dyn_lds, e->stream, kp);
+    } else {
+      HIP_TRY(hipFuncSetAttribute((const void*)biwfa_align_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+      hipLaunchKernelGGL(biwfa_align_kernel<false>, dim3(nslots), dim3(WG), dyn_lds, e->stream, kp);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    kernel_ms += ms;
+    ++launches;
+    // ---- D2H
+    hres.resize((size_t)n);
+    static_assert(sizeof(awv_result) == sizeof(DevResult), "result layout");
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    HIP_TRY(hipMemcpyAsync(hres.data(), e->d_results.p, (size_t)n * sizeof(awv_result), hipMemcpyDeviceToHost, e->stream));
+    unsigned long long hstat[1 + STAT_N];
+    HIP_TRY(hipMemcpyAsync(hstat, e->d_counters.p, sizeof(hstat), hipMemcpyDeviceToHost, e->stream));
+    const bool want_cigar = sink && !(e->cfg.flags & AWV_F_KEEP_ON_DEVICE);
+    if (want_cigar) {
+      e->h_cigar.resize((size_t)arena + 64);
+      HIP_TRY(hipMemcpyAsync(e->h_cigar.data(), e->d_cigar.p, (size_t)arena, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    d2h_ms += ms;
+    for (int i = 0; i < STAT_N; ++i) stat_tot[i] += hstat[1 + i];
+    if (out) std::memcpy(out + first, hres.data(), (size_t)n * sizeof(awv_result));
+    if (sink) {
+      const int rc = sink(user, first, n, hres.data(), want_cigar ? e->h_cigar.data() : nullptr);
+      if (rc != 0) return fail(AWV_ERR_SINK, "sink callback returned " + std::to_string(rc));
+    }
+    first += n;
+  }
+  e->stats.kernel_ms = kernel_ms;
+  e->stats.h2d_ms = h2d_ms;
+  e->stats.d2h_ms = d2h_ms;
+  e->stats.launches = launches;
+  e->stats.cell_steps = stat_tot[STAT_CELLS];
+  e->stats.extend_steps = stat_tot[STAT_EXTEND];
+  e->stats.n_breakpoints = stat_tot[STAT_BREAKPOINTS];
+  e->stats.n_base = stat_tot[STAT_BASE];
+  e->stats.overlap_scans = stat_tot[STAT_OVERLAP];
+  e->stats.aligned_bp = stat_tot[STAT_ALIGNED_BP];
+  e->stats.pairs_completed = stat_tot[STAT_PAIRS];
+  e->stats.scratch_bytes = e->ring_mem.bytes() + e->hist_mem.bytes() + e->ev_mem.bytes();
+  return AWV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int awv_abi_version(void) { return AWV_ABI_VERSION; }
+
+const char* awv_last_error(void) { return g_last_error.c_str(); }
+
+int awv_engine_create(const awv_engine_config* cfg, awv_engine** out) {
+  if (!out) return fail(AWV_ERR_ARG, "engine_create: null out");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t err = hipGetDeviceCount(&ndev);
+  if (err != hipSuccess || ndev <= 0)
+    return fail(AWV_ERR_NO_DEVICE, std::string("no HIP device available (") + hipGetErrorString(err) +
+                                       "): liballwave_hip has no CPU fallback");
+  awv_engine* e = new awv_engine();
+  if (cfg) e->cfg = *cfg;
+  e->device = e->cfg.device;
+  if (e->device < 0 || e->device >= ndev) {
+    delete e;
+    return fail(AWV_ERR_ARG, "engine_create: device ordinal out of range");
+  }
+  auto bail = [&](hipError_t he, const char* what) {
+    std::string m = std::string(what) + ": " + hipGetErrorString(he);
+    awv_engine_destroy(e);
+    return fail(AWV_ERR_HIP, m);
+  };
+  hipError_t he;
+  if ((he = hipSetDevice(e->device)) != hipSuccess) return bail(he, "hipSetDevice");
+  hipDeviceProp_t prop;
+  if ((he = hipGetDeviceProperties(&prop, e->device)) != hipSuccess) return bail(he, "hipGetDeviceProperties");
+  e->num_cus = prop.multiProcessorCount;
+  if ((he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess) return bail(he, "hipStreamCreate");
+  if ((he = hipEventCreate(&e->ev0)) != hipSuccess) return bail(he, "hipEventCreate");
+  if ((he = hipEventCreate(&e->ev1)) != hipSuccess) return bail(he, "hipEventCreate");
+  *out = e;
+  return AWV_OK;
+}
+
+void awv_engine_destroy(awv_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  e->seqs.release();
+  e->ring_mem.release();
+  e->hist_mem.release();
+  e->ev_mem.release();
+  e->d_pair_q.release();
+  e->d_pair_t.release();
+  e->d_pair_rc.release();
+  e->d_cigar_off.release();
+  e->d_results.release();
+  e->d_cigar.release();
+  e->d_counters.release();
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int awv_engine_set_sequences(awv_engine* e, int32_t n, const uint8_t* concat_bytes, const uint64_t* offsets) {
+  if (!e) return fail(AWV_ERR_ARG, "null engine");
+  return upload_seqset(e, e->seqs, n, concat_bytes, offsets);
+}
+
+int awv_align_pairs(awv_engine* e, const awv_penalties* pen, const awv_pair* pairs, int64_t npairs, awv_result* out,
+                    awv_sink sink, void* user) {
+  if (!e) return fail(AWV_ERR_ARG, "null engine");
+  if (e->seqs.n == 0 && npairs > 0) return fail(AWV_ERR_STATE, "align_pairs before set_sequences");
+  return align_core(e, e->seqs, pen, pairs, npairs, out, sink, user);
+}
+
+namespace {
+struct OneSink {
+  uint8_t* buf;
+  size_t cap;
+  int rc;
+};
+int one_sink(void* user, int64_t, int64_t n, const awv_result* r, const uint8_t* arena) {
+  OneSink* o = (OneSink*)user;
+  if (n != 1 || !arena) return 1;
+  if (r[0].status == AWV_ST_COMPLETED) {
+    if (r[0].cigar_len > o->cap) { o->rc = AWV_ERR_ARG; return 2; }
+    std::memcpy(o->buf, arena + r[0].cigar_off, r[0].cigar_len);
+  }
+  return 0;
+}
+}  // namespace
+
+int awv_align_one(awv_engine* e, const awv_penalties* pen, const uint8_t* pattern, int32_t plen, const uint8_t* text,
+                  int32_t tlen, awv_result* result, uint8_t* cigar_buf, size_t cigar_cap) {
+  if (!e || !result || plen < 0 || tlen < 0 || (plen > 0 && !pattern) || (tlen > 0 && !text))
+    return fail(AWV_ERR_ARG, "align_one: bad argument");
+  if (cigar_cap < (size_t)plen + (size_t)tlen) return fail(AWV_ERR_ARG, "align_one: cigar buffer needs plen + tlen bytes");
+  SeqSet tmp;
+  std::vector<uint8_t> cat((size_t)plen + (size_t)tlen + 1);
+  if (plen) std::memcpy(cat.data(), pattern, (size_t)plen);
+  if (tlen) std::memcpy(cat.data() + plen, text, (size_t)tlen);
+  const uint64_t offs[3] = {0, (uint64_t)plen, (uint64_t)plen + (uint64_t)tlen};
+  int rc = upload_seqset(e, tmp, 2, cat.data(), offs);
+  if (rc == AWV_OK) {
+    const awv_pair p{0, 1, 0};
+    OneSink os{cigar_buf, cigar_cap, AWV_OK};
+    const int32_t saved_flags = e->cfg.flags;
+    e->cfg.flags &= ~AWV_F_KEEP_ON_DEVICE;
+    rc = align_core(e, tmp, pen, &p, 1, result, one_sink, &os);
+    e->cfg.flags = saved_flags;
+    if (rc == AWV_ERR_SINK && os.rc != AWV_OK) rc = fail(os.rc, "align_one: cigar buffer too small");
+  }
+  tmp.release();
+  return rc;
+}
+
+int awv_engine_stats(const awv_engine* e, awv_stats* out) {
+  if (!e || !out) return fail(AWV_ERR_ARG, "stats: null argument");
+  *out = e->stats;
+  return AWV_OK;
+}
+
+}  // extern "C"
