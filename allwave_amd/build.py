@@ -2,7 +2,7 @@
 
   liballwave_hip.so   HIP kernels + C ABI (include/allwave_hip.h)      <- the product
   liballwave_host.so  C++ mirror of allwave's host API over the C ABI  <- the product's host side
-The CPU oracle (oracle/liboracle.so) is built by oracle/Makefile and is test infrastructure.
+The CPU oracle under oracle/ has its own Makefile and is test infrastructure; nothing here touches it.
 """
 import os
 import shutil

@@ -202,11 +202,14 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   }
   int ring = 4;
   while (ring < dp.scope + 2) ring *= 2;
-  const int nslots_cfg = e->cfg.workgroups > 0 ? e->cfg.workgroups : 2 * e->num_cus;
+  const int nslots_cfg = e->cfg.workgroups > 0 ? e->cfg.workgroups : 3 * e->num_cus;
   const int64_t max_batch = e->cfg.max_batch_pairs > 0 ? e->cfg.max_batch_pairs : (int64_t)1 << 20;
   const uint64_t max_arena = e->cfg.max_arena_bytes > 0 ? (uint64_t)e->cfg.max_arena_bytes : (uint64_t)8 << 30;
   // base-case capacities: score_remaining <= 250 or both lengths <= 100
-  const long long sb = std::max<long long>(FALLBACK_MIN_SCORE, worst_case_penalty(dp, FALLBACK_MIN_LENGTH));
+  // A sub-problem that ends in an indel component pays that gap's open on top of the
+  // score_remaining its parent hands down (the reverse aligner starts with the open pre-paid).
+  const long long sb = std::max<long long>(FALLBACK_MIN_SCORE + std::max(dp.o1, dp.o2),
+                                           worst_case_penalty(dp, FALLBACK_MIN_LENGTH));
   if (sb > 4000) return fail(AWV_ERR_PENALTIES, "penalties too large for the base-case history");
   const int sb_cap = (int)sb;
   const int wb_cap = ((2 * sb_cap + 9) + 63) & ~63;

@@ -130,7 +130,8 @@ class Engine:
         Returns (results structured array, list of op-byte strings or None)."""
         pen = scores if isinstance(scores, Penalties) else Penalties.from_scores(scores)
         if not (isinstance(pairs, np.ndarray) and pairs.dtype == PAIR_DTYPE):
-            a = np.asarray(pairs, dtype=np.int32).reshape(len(pairs), -1)
+            a = np.asarray(pairs, dtype=np.int32)
+            a = a.reshape(len(a), -1) if len(a) else np.zeros((0, 2), dtype=np.int32)
             p = np.zeros(len(a), dtype=PAIR_DTYPE)
             if len(a):
                 p["q_idx"], p["t_idx"] = a[:, 0], a[:, 1]

@@ -66,7 +66,7 @@ typedef struct awv_engine awv_engine;
 
 typedef struct {
   int32_t device;          /* HIP device ordinal */
-  int32_t workgroups;      /* persistent workgroups (0 = engine default: 2 per CU) */
+  int32_t workgroups;      /* persistent workgroups (0 = engine default: 3 per CU) */
   int64_t max_batch_pairs; /* pairs per launch (0 = default) */
   int64_t max_arena_bytes; /* CIGAR arena budget per launch (0 = default 8 GiB) */
   int32_t flags;           /* AWV_F_* */

@@ -787,6 +787,7 @@ static int bialign_base(awo_aligner_t* A, int cb, int ce, int* penalty) {
   if (score < 0) return score;
   if (A->stats) A->stats->n_base++;
   if (penalty) *penalty = score;
+  if (getenv("AWO_DEBUG")) fprintf(stderr, "[awo]   base score %d end_k %d\n", score, s->end_k);
   return wf_backtrace_affine(A, s);
 }
 
@@ -982,6 +983,7 @@ static int bialign_find_breakpoint(awo_aligner_t* A, int cb, int ce, bialign_bre
     last_wf_forward = true;
   }
   if (A->stats) A->stats->n_breakpoints++;
+  if (getenv("AWO_DEBUG")) fprintf(stderr, "[awo]   bp score %d sf %d sr %d kf %d off_f %d comp %d (final scores f %d r %d)\n", bp->score, bp->score_forward, bp->score_reverse, bp->k_forward, bp->offset_forward, bp->component, score_forward, score_reverse);
   return WF_STATUS_OK;
 }
 
@@ -1003,6 +1005,7 @@ static int bialign_alignment(awo_aligner_t* A, int pb, int pe, int tb, int te, i
     return A->error;
   }
   seqs_set_bounds(A, pb, pe, tb, te);
+  if (getenv("AWO_DEBUG")) fprintf(stderr, "[awo] level %d p[%d,%d) t[%d,%d) cb %d ce %d score_remaining %d\n", level, pb, pe, tb, te, cb, ce, score_remaining);
   /* fall back to regular WFA */
   if (score_remaining <= WF_BIALIGN_FALLBACK_MIN_SCORE) return bialign_base(A, cb, ce, penalty);
   bialign_breakpoint_t bp;

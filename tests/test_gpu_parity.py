@@ -1,0 +1,177 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, must equal the CPU oracle
+bit for bit -- penalties and CIGAR op bytes -- on the same seeded inputs, on the committed golden
+fixtures, and satisfy size-independent properties at BASELINE.json's full shapes."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from util import DEFAULT_2P, EDIT, PENALTY_SETS, mutate, rand_seq, random_pair, rle
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def check_against_oracle(engine, oracle, seqs, pairs, scores):
+    engine.set_sequences(seqs)
+    res, cigs = engine.align_pairs(scores, pairs)
+    al = oracle.Aligner(scores)
+    for i, p in enumerate(pairs):
+        a, b = p[0], p[1]
+        pen, ops = al.align(seqs[a], seqs[b])
+        assert res["status"][i] == 0, (scores, i)
+        assert res["penalty"][i] == pen and res["score"][i] == -pen, (scores, i, len(seqs[a]), len(seqs[b]))
+        assert cigs[i] == ops, (scores, i, rle(cigs[i])[:60], rle(ops)[:60])
+        c = {k: ops.count(k.encode()) for k in "MXID"}
+        assert (res["num_matches"][i], res["num_mismatches"][i], res["num_ins"][i], res["num_del"][i]) == \
+               (c["M"], c["X"], c["I"], c["D"])
+        # parse_cigar_lengths of /root/reference/src/alignment.rs:320-344
+        assert res["q_end"][i] == c["M"] + c["X"] + c["D"] == len(seqs[a])
+        assert res["t_end"][i] == c["M"] + c["X"] + c["I"] == len(seqs[b])
+
+
+def test_golden_fixtures(engine):
+    with open(os.path.join(GOLDEN, "oracle_kats.json")) as f:
+        doc = json.load(f)
+    for case in doc["cases"]:
+        r, ops = engine.align_one(tuple(case["scores"]), case["pattern"].encode("latin1"),
+                                  case["text"].encode("latin1"))
+        assert r["status"] == 0 and r["penalty"] == case["penalty"], case["name"]
+        assert rle(ops) == case["cigar"], case["name"]
+
+
+def test_reference_kat_counts(engine):
+    """tests/integration_tests.rs:599-672 through the HIP path."""
+    ref = b"ATCG" * 25
+    q = bytearray(ref)
+    q[10] = ord("G"); q[20] = ord("C"); del q[30]; q.insert(40, ord("A"))
+    r, ops = engine.align_one(DEFAULT_2P, bytes(q), ref)
+    assert (r["num_mismatches"], r["num_ins"], r["num_del"], r["penalty"]) == (2, 1, 1, 30)
+
+
+@pytest.mark.parametrize("scores", PENALTY_SETS)
+def test_random_pairs_bit_exact(engine, oracle, scores):
+    rng = random.Random(1000 + (hash(scores) & 0xFFF))
+    seqs, pairs = [], []
+    for _ in range(150):
+        s, t = random_pair(rng, 1500)
+        seqs += [s, t]
+        pairs.append((len(seqs) - 2, len(seqs) - 1))
+    check_against_oracle(engine, oracle, seqs, pairs, scores)
+
+
+def test_edge_cases(engine, oracle):
+    """Empty and ragged inputs, single bases, the 100/101 length threshold (A.6), identical
+    sequences (end reached at score 0), all-gap alignments, non-ACGT and lower-case bytes."""
+    rng = random.Random(77)
+    s1k = rand_seq(rng, 1000)
+    seqs = [b"", b"A", b"C", b"ACGT", s1k, s1k, rand_seq(rng, 100), rand_seq(rng, 101), s1k[:100], s1k[:101],
+            s1k.lower(), b"N" * 300, b"ACGTN" * 60, bytes(range(256)) * 2, rand_seq(rng, 5000), b"A" * 700, b"AC" * 350]
+    n = len(seqs)
+    pairs = [(i, j) for i in range(n) for j in range(n)]
+    for scores in (DEFAULT_2P, EDIT):
+        check_against_oracle(engine, oracle, seqs, pairs, scores)
+
+
+def test_config1_all_pairs(engine, oracle):
+    """BASELINE.json configs[0]: 8 x 1 kbp, 5% divergence, scores 0,1,1,1, -p none => 56 pairs."""
+    from allwave_amd import synth
+    data, offs, _ = synth.generate(8, 1000, 0.05, 1)
+    seqs = [bytes(data[offs[i]:offs[i + 1]]) for i in range(8)]
+    pairs = synth.all_pairs(8)
+    assert len(pairs) == 56
+    check_against_oracle(engine, oracle, seqs, [tuple(p) for p in pairs], EDIT)
+
+
+def test_config2_sample_and_invariants(engine, oracle):
+    """BASELINE.json configs[1] shape (256 x 10 kbp, 5%, default 2-piece scores): a seeded sample
+    is compared bit-exact with the oracle; a larger slice is checked through properties that do
+    not need the oracle: full consumption, M/X columns verified against the sequences, CIGAR
+    re-scores to the reported penalty, and penalty(i,j) == penalty(j,i)."""
+    from allwave_amd import synth
+    data, offs, _ = synth.generate(256, 10000, 0.05, 2)
+    allp = synth.all_pairs(256)
+    engine.set_sequences((data, offs))
+    sample = allp[::1571][:40]
+    res, cigs = engine.align_pairs(DEFAULT_2P, sample)
+    al = oracle.Aligner(DEFAULT_2P)
+    for i, (a, b) in enumerate(sample):
+        pen, ops = al.align(bytes(data[offs[a]:offs[a + 1]]), bytes(data[offs[b]:offs[b + 1]]))
+        assert res["status"][i] == 0 and res["penalty"][i] == pen and cigs[i] == ops, (a, b)
+    sl = np.concatenate([allp[:300], allp[:300][:, ::-1]])
+    res, cigs = engine.align_pairs(DEFAULT_2P, sl)
+    assert (res["status"] == 0).all()
+    assert (res["penalty"][:300] == res["penalty"][300:]).all()  # symmetric penalties
+    for i, (a, b) in enumerate(sl[:300]):
+        p, t = bytes(data[offs[a]:offs[a + 1]]), bytes(data[offs[b]:offs[b + 1]])
+        rc, rescored = oracle.cigar_check(cigs[i], p, t, DEFAULT_2P)  # validator only (wfa.rs:105-176)
+        assert rc == 0 and rescored == res["penalty"][i]
+
+
+def test_reverse_complement_pairs(engine, oracle):
+    """q_revcomp aligns reverse_complement(query) (alignment.rs:178-190): upper-cases, unknown -> N."""
+    rng = random.Random(5)
+    comp = {65: 84, 84: 65, 67: 71, 71: 67, 97: 84, 116: 65, 99: 71, 103: 67}
+
+    def rc(s):
+        return bytes(comp.get(b, 78) for b in reversed(s))
+
+    t = rand_seq(rng, 1800)
+    qs = [rc(mutate(t, 0.05, rng)), rc(mutate(t, 0.1, rng)).lower(), rc(mutate(t, 0.02, rng, b"ACGTN"))]
+    seqs = qs + [t]
+    engine.set_sequences(seqs)
+    res, cigs = engine.align_pairs(DEFAULT_2P, [(i, 3, 1) for i in range(3)])
+    al = oracle.Aligner(DEFAULT_2P)
+    for i in range(3):
+        pen, ops = al.align(rc(qs[i]), t)
+        assert res["status"][i] == 0 and res["penalty"][i] == pen and cigs[i] == ops
+
+
+def test_shard_invariance(engine):
+    """K logical shards of the pair list give the same results as one call
+    (the multi-GPU decomposition, exercised on one device)."""
+    from allwave_amd import synth
+    data, offs, _ = synth.generate(12, 2000, 0.05, 11)
+    pairs = synth.all_pairs(12)
+    engine.set_sequences((data, offs))
+    res1, c1 = engine.align_pairs(DEFAULT_2P, pairs)
+    for k in (2, 4, 8):
+        got = {}
+        for r in range(k):
+            sub = pairs[r::k]
+            rs, cs = engine.align_pairs(DEFAULT_2P, sub)
+            for j, p in enumerate(sub):
+                got[tuple(p)] = (int(rs["penalty"][j]), cs[j])
+        for i, p in enumerate(pairs):
+            assert got[tuple(p)] == (int(res1["penalty"][i]), c1[i])
+
+
+def test_engine_stats_and_batching(engine):
+    from allwave_amd import ffi, synth
+    data, offs, _ = synth.generate(10, 1500, 0.05, 3)
+    pairs = synth.all_pairs(10)
+    e2 = ffi.Engine(max_batch_pairs=7)  # forces 13 launches
+    try:
+        e2.set_sequences((data, offs))
+        r2, c2 = e2.align_pairs(DEFAULT_2P, pairs)
+        st = e2.stats()
+        assert st.launches == 13 and st.pairs_completed == 90 and st.cell_steps > 0
+        assert st.aligned_bp == sum(int(offs[a + 1] - offs[a]) for a, _ in pairs)
+    finally:
+        e2.close()
+    engine.set_sequences((data, offs))
+    r1, c1 = engine.align_pairs(DEFAULT_2P, pairs)
+    assert (r1["penalty"] == r2["penalty"]).all() and c1 == c2
+
+
+def test_bad_arguments(engine):
+    from allwave_amd import ffi
+    engine.set_sequences([b"ACGT", b"ACGA"])
+    with pytest.raises(ffi.EngineError):
+        engine.align_pairs((1, 5, 8, 2), [(0, 1)])  # match != 0
+    with pytest.raises(ffi.EngineError):
+        engine.align_pairs(DEFAULT_2P, [(0, 2)])     # index out of range
+    res, _ = engine.align_pairs(DEFAULT_2P, np.zeros((0, 2), dtype=np.int32))
+    assert len(res) == 0

@@ -1,0 +1,157 @@
+"""CPU tests (-m "not gpu") that pin the oracle.
+
+The reference holds no golden CIGAR/score for this path ("parity unpinned"), so the
+oracle is pinned by (i) an independent Gotoh full DP (optimality), (ii) CIGAR validity + re-scoring
+(/root/reference/src/wfa.rs:105-176 restated in oracle/cigar_check.c), (iii) every known-answer
+property the reference's own tests assert on this path, (iv) the committed fixtures under
+tests/golden/ (oracle-generated, labelled as such; they freeze tie-breaking across rounds).
+"""
+import json
+import os
+import random
+
+import pytest
+
+from util import DEFAULT_2P, EDIT, PENALTY_SETS, mutate, rand_seq, random_pair, rle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def counts(ops):
+    return {c: ops.count(c.encode()) for c in "MXID"}
+
+
+def test_kat_alignment_correctness(oracle):
+    """tests/integration_tests.rs:599-672: exactly 2 mismatches, 1 insertion, 1 deletion
+    (standard CIGAR letters after the I/D swap) with the default scores => penalty 2*5+2*(8+2)."""
+    ref = b"ATCG" * 25
+    q = bytearray(ref)
+    q[10] = ord("G")
+    q[20] = ord("C")
+    del q[30]
+    q.insert(40, ord("A"))
+    pen, ops = oracle.Aligner(DEFAULT_2P).align(bytes(q), ref)
+    c = counts(ops)
+    assert (c["X"], c["I"], c["D"]) == (2, 1, 1)
+    assert pen == 30
+    s = rle(ops)
+    assert s.count("X") == 2 and s.count("I") == 1 and s.count("D") == 1
+
+
+def test_kat_identical(oracle):
+    """tests/integration_tests.rs:216-260: identical sequences => all matches, identity 1."""
+    rng = random.Random(5)
+    s = rand_seq(rng, 5000)
+    for scores in (DEFAULT_2P, EDIT):
+        pen, ops = oracle.Aligner(scores).align(s, s)
+        assert pen == 0 and ops == b"M" * 5000
+
+
+def test_kat_debug_probes(oracle):
+    """Expected shapes printed by the reference's lib_wfa2 probes: one X at column 8
+    (tests/debug/check_wfa_ops.rs:15-20); 8 matches + 2 gap ops whose letter depends on which
+    side is longer (tests/debug/test_cigar_interpretation.rs:38-116, test_wfa_order.rs:1-31)."""
+    a = oracle.Aligner((0, 4, 6, 2))  # AffineWavefronts::default() penalties [RECALLED]
+    pen, ops = a.align(b"ACGTACGTACGT", b"ACGTACGTTCGT")
+    assert ops == b"MMMMMMMMXMMM" and pen == 4
+    pen, ops = a.align(b"ACGTACGTAA", b"ACGTACGT")  # query longer: 'D' consumes the query
+    assert ops == b"MMMMMMMMDD"
+    pen, ops = a.align(b"ACGTACGT", b"ACGTACGTAA")  # target longer: 'I' consumes the target
+    assert ops == b"MMMMMMMMII"
+    pen, ops = oracle.Aligner((0, 5, 8, 2)).align(b"ACGTACGTACGT", b"ACGTACGTAC")
+    assert ops == b"MMMMMMMMMMDD" and pen == 12
+
+
+def test_edit_mode_is_gap_affine(oracle):
+    """allwave's "edit distance" builds gap-affine (x,x,x)
+    (/root/reference/src/alignment.rs:265-271), so a 1-bp indel costs 2x, not x."""
+    pen, ops = oracle.Aligner(EDIT).align(b"ACGTTACGT", b"ACGTACGT")
+    assert pen == 2 and counts(ops)["D"] == 1
+
+
+def test_empty_and_trivial(oracle):
+    a = oracle.Aligner(DEFAULT_2P)
+    assert a.align(b"", b"") == (0, b"")
+    assert a.align(b"", b"ACGT") == (16, b"IIII")       # min(8+2*4, 24+4)
+    assert a.align(b"ACGT", b"") == (16, b"DDDD")
+    pen, ops = a.align(b"A", b"C")
+    assert pen == 5 and ops == b"X"
+    pen, ops = a.align(b"A" * 40, b"")
+    assert pen == 64 and ops == b"D" * 40               # second piece: 24 + 40
+
+
+def test_penalties_rejected(oracle):
+    for bad in [(1, 5, 8, 2), (0, 0, 8, 2), (0, 5, 8, 0), (0, 5, -1, 2), (0, 5, 8, 2, 24, 0)]:
+        with pytest.raises(ValueError):
+            oracle.Aligner(bad)
+
+
+@pytest.mark.parametrize("scores", PENALTY_SETS)
+def test_optimal_and_valid_random(oracle, scores):
+    """penalty == Gotoh DP == re-scored CIGAR, BiWFA and plain WFA agree on the penalty."""
+    rng = random.Random(hash(scores) & 0xFFFF)
+    al = oracle.Aligner(scores)
+    for it in range(70):
+        s, t = random_pair(rng, 1200)
+        st = oracle.Stats()
+        pen, ops = al.align(s, t, st)
+        pen_u, ops_u = al.align_unidirectional(s, t)
+        g = oracle.gotoh_penalty(s, t, scores)
+        rc, rescored = oracle.cigar_check(ops, s, t, scores)
+        rc_u, rescored_u = oracle.cigar_check(ops_u, s, t, scores)
+        assert rc == 0 and rc_u == 0, (scores, len(s), len(t))
+        assert pen == g == rescored == pen_u == rescored_u, (scores, len(s), len(t))
+
+
+def test_biwfa_recursion_exercised(oracle):
+    """A 3 kbp / 10% pair must go through breakpoints, base cases and several levels."""
+    rng = random.Random(3)
+    s = rand_seq(rng, 3000)
+    t = mutate(s, 0.10, rng)
+    st = oracle.Stats()
+    pen, ops = oracle.Aligner(DEFAULT_2P).align(s, t, st)
+    assert st.n_breakpoints >= 3 and st.n_base >= 4 and st.max_level >= 2
+    assert pen == oracle.gotoh_penalty(s, t, DEFAULT_2P)
+    assert oracle.cigar_check(ops, s, t, DEFAULT_2P) == (0, pen)
+
+
+def test_raw_bytes_and_case(oracle):
+    """Bytes are compared verbatim: case-sensitive, 'N' == 'N' (SURVEY Appendix B)."""
+    a = oracle.Aligner(EDIT)
+    assert a.align(b"acgt", b"ACGT")[0] == 4
+    assert a.align(b"ACNNGT", b"ACNNGT") == (0, b"MMMMMM")
+    rng = random.Random(9)
+    alpha = bytes(range(256))
+    for _ in range(30):
+        s = rand_seq(rng, rng.choice([10, 120, 400]), alpha)
+        t = mutate(s, 0.2, rng, alpha)
+        pen, ops = a.align(s, t)
+        assert pen == oracle.gotoh_penalty(s, t, EDIT)
+        assert oracle.cigar_check(ops, s, t, EDIT) == (0, pen)
+
+
+def test_golden_fixtures(oracle):
+    """tests/golden/oracle_kats.json (written by tests/golden/make_golden.py from this oracle)."""
+    with open(os.path.join(GOLDEN, "oracle_kats.json")) as f:
+        doc = json.load(f)
+    assert doc["provenance"].startswith("oracle-generated")
+    for case in doc["cases"]:
+        pen, ops = oracle.Aligner(tuple(case["scores"])).align(case["pattern"].encode("latin1"),
+                                                              case["text"].encode("latin1"))
+        assert pen == case["penalty"], case["name"]
+        assert rle(ops) == case["cigar"], case["name"]
+
+
+def test_all_pairs_driver(oracle):
+    """The thread-pool driver (bench cpu_baseline leg) agrees with single calls."""
+    import numpy as np
+    from allwave_amd import synth
+    data, offs, _ = synth.generate(6, 600, 0.05, 7)
+    pairs = synth.all_pairs(6)
+    secs, res, st, paf = oracle.all_pairs(data, offs, pairs, DEFAULT_2P, nthreads=2, want_paf=True)
+    assert len(res) == 30 and (res["status"] == 0).all() and paf > 0
+    al = oracle.Aligner(DEFAULT_2P)
+    for i, (a, b) in enumerate(pairs):
+        pen, ops = al.align(bytes(data[offs[a]:offs[a + 1]]), bytes(data[offs[b]:offs[b + 1]]))
+        assert res["penalty"][i] == pen and res["cigar_len"][i] == len(ops)
+        assert res["num_matches"][i] == ops.count(b"M")
