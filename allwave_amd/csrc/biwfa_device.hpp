@@ -30,10 +30,12 @@ constexpr int MAX_RING = 128;
 constexpr int NCOMP = 5;
 constexpr int32_t OFF_NULL = INT32_MIN / 2;
 constexpr int32_t NULLISH = INT32_MIN / 4;    // any value below is a NULL(+n)
+constexpr int32_t NULL16 = -16384;            // NULL as stored in 16-bit rows (NULL16 + NULL16 and NULL16 + tlen + 1 stay negative)
 enum { C_M = 0, C_I1 = 1, C_I2 = 2, C_D1 = 3, C_D2 = 4 };
 constexpr int FALLBACK_MIN_SCORE = 250;
 constexpr int FALLBACK_MIN_LENGTH = 100;
-constexpr int STACK_CAP = 192;
+constexpr int STACK_CAP = 96;
+constexpr int COL_PAD = 576;  // columns of slack either side of a row: whole-wave vector loads stay inside it
 
 // per-pair status (allwave_hip.h AWV_ST_*)
 constexpr int ST_OK = 0, ST_CAPACITY = 1, ST_INTERNAL = 2, ST_MAX_STEPS = 3;
@@ -49,7 +51,25 @@ struct DevResult {  // mirrors awv_result
   int32_t num_matches, num_mismatches, num_ins, num_del, q_end, t_end;
 };
 
-enum { STAT_CELLS = 0, STAT_EXTEND, STAT_BREAKPOINTS, STAT_BASE, STAT_OVERLAP, STAT_ALIGNED_BP, STAT_PAIRS, STAT_N };
+enum { STAT_CELLS = 0, STAT_EXTEND, STAT_BREAKPOINTS, STAT_BASE, STAT_OVERLAP, STAT_ALIGNED_BP, STAT_PAIRS,
+       // cycle stamps (s_memtime, wave 0) -- only filled by the -DAWV_PROF diagnostic build
+       STAT_T_TOTAL, STAT_T_BI_COMPUTE, STAT_T_BI_BARRIER, STAT_T_BI_FINALIZE, STAT_T_OVERLAP, STAT_T_BASE_STEPS,
+       STAT_T_BACKTRACE, STAT_T_EMIT, STAT_N_PASSES,
+       STAT_T_CR_LOAD, STAT_T_CR_ALU, STAT_T_CR_EXTEND, STAT_T_CR_STORE, STAT_T_CR_REDUCE, STAT_N };
+
+#ifdef AWV_PROF
+#define PROF_DRAIN() __builtin_amdgcn_s_waitcnt(0)
+#define PROF_NOW() __builtin_readcyclecounter()
+#define PROF_ADD(slot, t0) do { if (threadIdx.x == 0) lstats[slot] += __builtin_readcyclecounter() - (t0); } while (0)
+#define PROF_INC(slot) do { if (threadIdx.x == 0) lstats[slot] += 1; } while (0)
+#define PROF_ADD_L(slot, t0) do { if (threadIdx.x == 0) sh.prof[(slot) - STAT_T_CR_LOAD] += __builtin_readcyclecounter() - (t0); } while (0)
+#else
+#define PROF_ADD_L(slot, t0) do { (void)(t0); } while (0)
+#define PROF_DRAIN() do { } while (0)
+#define PROF_NOW() 0ULL
+#define PROF_ADD(slot, t0) do { (void)(t0); } while (0)
+#define PROF_INC(slot) do { } while (0)
+#endif
 
 struct KParams {
   const uint8_t* seq[4];  // 0 fwd, 1 reversed, 2 reverse-complement, 3 reversed reverse-complement
@@ -62,12 +82,14 @@ struct KParams {
   DevPenalties pen;
   int ring;        // power of two >= scope + 2
   int wcap;        // columns per ring row
-  int32_t* ring_mem;
-  size_t ring_slot_stride;  // int32 elements per workgroup slot
+  void* ring_mem;
+  size_t ring_slot_stride;  // bytes per workgroup slot
+  int lds_meta_bytes;  // dynamic LDS: metadata region (16-byte multiple)
+  int lds_seq_bytes;   // dynamic LDS: sequence staging region (0 = sequences stay in global memory)
   int sb_cap;      // base-case score capacity
   int wb_cap;      // base-case columns per row
-  int32_t* hist_mem;
-  size_t hist_slot_stride;
+  void* hist_mem;
+  size_t hist_slot_stride;  // bytes per workgroup slot
   uint32_t* ev_mem;
   size_t ev_slot_stride;
   uint8_t* cigar;
@@ -78,55 +100,210 @@ struct KParams {
 };
 
 struct RowMeta { int lo, hi; };
+constexpr int K_BIG = 1 << 28;  // an empty row is {K_BIG, -K_BIG}: min/max hulls ignore it for free
+#define ROW_EMPTY RowMeta{K_BIG, -K_BIG}
 struct Acc { int hull_lo[NCOMP]; int hull_hi[NCOMP]; int maxak; int oob; };
 struct Task { int pb, pe, tb, te, cb, ce, score_remaining; };
 struct Breakpoint { int score, sf, sr, kf, kr, off_f, off_r, comp; };
 
+// LDS: a small static part plus one dynamic region carved per launch (sizes depend on the
+// penalties' ring depth, the base-case score capacity and the sequence staging budget):
+//   [ bi_meta[2][NCOMP][ring] | bi_A[2][ring] | bi_oob[2][ring] | firstk[scope*NCOMP] ]  (BiWFA search)
+//   aliased with base_meta[(sb_cap+1)*NCOMP]                                             (base case)
+//   [ seq: the sub-problem's pattern and text bytes, 8-byte padded ]
+struct Lds {
+  RowMeta* bi_meta;
+  int* bi_A;
+  int* bi_oob;
+  int* firstk;
+  RowMeta* base_meta;
+  uint8_t* seq;
+};
 struct Shared {
-  RowMeta bi_meta[2][NCOMP][MAX_RING];
-  int bi_A[2][MAX_RING];
-  int bi_oob[2][MAX_RING];
   Acc acc[3][2];
-  int firstk[MAX_RING * NCOMP];
   Task stack[STACK_CAP];
   int ext0[2];
+  unsigned long long prof[5];
   long long cur_pair;
   int error;
   int nev;
   int bt_total;
 };
 
+// Pointers that arrive inside the KParams struct are generic (flat) to the compiler; the hot
+// sequence reads go through explicit global-address-space pointers (global_load + SGPR base).
+typedef const __attribute__((address_space(1))) uint8_t* gseq_t;
+typedef uint64_t u64_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ gseq_t to_global(const uint8_t* p) { return (gseq_t)(uintptr_t)p; }
+
 struct SubCtx {
   int plen, tlen;
-  const uint8_t* P[2];
-  const uint8_t* T[2];
+  gseq_t P[2];
+  gseq_t T[2];
   int kmin[2];
   int wcols;
+  int seq_lds;       // 1: this sub-problem's pattern/text bytes are staged in LDS
+  int p_off, t_off;  // byte offsets of pattern / text in Lds::seq (8-byte aligned, 8-byte padded)
 };
 
 __device__ __forceinline__ bool row_empty(const RowMeta& m) { return m.lo > m.hi; }
 
-__device__ __forceinline__ uint64_t ld64u(const uint8_t* p) {
-  uint64_t v;
-  __builtin_memcpy(&v, p, 8);
+// Values read from LDS / computed from them are uniform across the workgroup by construction but
+// arrive in vector registers; readfirstlane moves them to SGPRs so the step planning, row offsets
+// and control flow run on the scalar unit (and stop eating the VGPR budget).
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ RowMeta uni(const RowMeta& m) { return RowMeta{uni(m.lo), uni(m.hi)}; }
+
+__device__ __forceinline__ uint64_t ld64u(gseq_t p) {
+  return *(const __attribute__((address_space(1))) u64_unaligned*)p;
+}
+
+// wave64 max-reduction on the DPP network (no LDS traffic): row_shr 1/2/4/8 leaves each row's max
+// in its lane 15, row_bcast15 / row_bcast31 fold the four rows; lane 63 holds the result.
+__device__ __forceinline__ int wave_max_i32(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x111, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x112, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x114, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x118, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x142, 0xa, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x143, 0xc, 0xf, false));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row storage: OffT = int16_t (8 diagonals per 16-byte lane vector; used when every offset fits,
+// i.e. text length < 32760) or int32_t (4 per vector).  Arithmetic is always int32 in registers
+// with WFA2's NULL = INT32_MIN/2 (A.1).  int16 rows store NULL(+n) as -1 and clamp offsets past
+// the text end to tlen+1: both are invisible to every comparison the algorithm makes (a NULL(+n)
+// only ever meets max() against real offsets or the out-of-bounds test; an h > tlen offset stays
+// out of bounds under +1 / diagonal shifts and only ever wins max() or fails the bounds test).
+// ---------------------------------------------------------------------------------------------
+template <typename OffT> struct OffTraits;
+template <> struct OffTraits<int32_t> { static constexpr int VEC = 4; };
+template <> struct OffTraits<int16_t> { static constexpr int VEC = 4; };
+
+template <typename OffT>
+__device__ __forceinline__ int32_t off_load1(const OffT* p) {
+  const int32_t v = (int32_t)*p;
+  if (sizeof(OffT) == 2) return v < 0 ? OFF_NULL : v;
   return v;
 }
 
-__device__ __forceinline__ int wave_max_i32(int v) {
+template <typename OffT, int VEC>
+__device__ __forceinline__ void off_load_vec(const OffT* p, int32_t (&out)[VEC]) {
+  OffT tmp[VEC];
+  __builtin_memcpy(tmp, p, sizeof(tmp));  // one 16-byte load (element-aligned only)
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-  return v;
+  for (int j = 0; j < VEC; ++j) {
+    const int32_t v = (int32_t)tmp[j];
+    out[j] = (sizeof(OffT) == 2 && v < 0) ? OFF_NULL : v;
+  }
+}
+
+// Buffer addressing for the hot row accesses: one SGPR descriptor per arena, an SGPR byte offset
+// per row, one shared VGPR column offset per lane and the k-1/k/k+1 shift as an immediate.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)min(bytes, (size_t)0x7FFFFFFF), 0x00020000);
+}
+
+template <typename OffT>
+__device__ __forceinline__ void buf_load_vec(rsrc_t r, int voff, int soff, int32_t (&out)[4]) {
+  if (sizeof(OffT) == 2) {
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    const int32_t a = (int32_t)raw[0], b = (int32_t)raw[1];
+    out[0] = (a << 16) >> 16;
+    out[1] = a >> 16;
+    out[2] = (b << 16) >> 16;
+    out[3] = b >> 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = out[j] < 0 ? OFF_NULL : out[j];
+  } else {
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = (int32_t)raw[j];
+  }
+}
+
+template <typename OffT> struct RawVec;
+template <> struct RawVec<int16_t> { unsigned int w[2]; };
+template <> struct RawVec<int32_t> { unsigned int w[4]; };
+
+template <typename OffT>
+__device__ __forceinline__ RawVec<OffT> buf_load_raw(rsrc_t r, int voff, int soff) {
+  RawVec<OffT> o;
+  if constexpr (sizeof(OffT) == 2) {
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    o.w[0] = raw[0]; o.w[1] = raw[1];
+  } else {
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    o.w[0] = raw[0]; o.w[1] = raw[1]; o.w[2] = raw[2]; o.w[3] = raw[3];
+  }
+  return o;
+}
+
+template <typename OffT>
+__device__ __forceinline__ void unpack_raw(const RawVec<OffT>& r, int32_t (&out)[4]) {
+  if constexpr (sizeof(OffT) == 2) {
+    const int32_t a = (int32_t)r.w[0], b = (int32_t)r.w[1];
+    out[0] = (a << 16) >> 16;
+    out[1] = a >> 16;
+    out[2] = (b << 16) >> 16;
+    out[3] = b >> 16;  // a stored NULL is NULL16 (negative): every consumer treats any negative as NULL
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = (int32_t)r.w[j];
+  }
+}
+
+template <typename OffT>
+__device__ __forceinline__ void buf_store_vec(rsrc_t r, int voff, int soff, const int32_t (&v)[4], int tlen) {
+  if (sizeof(OffT) == 2) {
+    int32_t c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = (v[j] < 0 ? NULL16 : min(v[j], tlen + 1)) & 0xFFFF;
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 raw;
+    raw[0] = (unsigned)(c[0] | (c[1] << 16));
+    raw[1] = (unsigned)(c[2] | (c[3] << 16));
+    __builtin_amdgcn_raw_buffer_store_b64(raw, r, voff, soff, 0);
+  } else {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 raw;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) raw[j] = (unsigned)v[j];
+    __builtin_amdgcn_raw_buffer_store_b128(raw, r, voff, soff, 0);
+  }
+}
+
+template <bool BASE, typename OffT>
+__device__ __forceinline__ int row_off(const KParams& kp, int dir, int comp, int score) {
+  if (score < 0) score = 0;
+  if (BASE) return (int)(((unsigned)score * NCOMP + comp) * (unsigned)kp.wb_cap * (unsigned)sizeof(OffT));
+  return (int)((((unsigned)(dir * NCOMP + comp)) * kp.ring + (unsigned)(score & (kp.ring - 1))) * (unsigned)kp.wcap *
+               (unsigned)sizeof(OffT));
+}
+
+template <typename OffT, int VEC>
+__device__ __forceinline__ void off_store_vec(OffT* p, const int32_t (&v)[VEC], int tlen) {
+  OffT tmp[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    if (sizeof(OffT) == 2) tmp[j] = (OffT)(v[j] < 0 ? NULL16 : min(v[j], tlen + 1));
+    else tmp[j] = (OffT)v[j];
+  }
+  __builtin_memcpy(p, tmp, sizeof(tmp));
 }
 
 // bounded LCP of pattern[v..] / text[h..] (A.4), 8 bytes per iteration
-__device__ __forceinline__ int extend_lcp(const uint8_t* P, const uint8_t* T, int v, int h, int plen, int tlen,
+__device__ __forceinline__ int extend_lcp(gseq_t P, gseq_t T, int v, int h, int plen, int tlen,
                                           unsigned& iters) {
   const int rem = min(plen - v, tlen - h);
-  const uint8_t* pp = P + v;
-  const uint8_t* tp = T + h;
+  gseq_t pp = P + (unsigned)v;
+  gseq_t tp = T + (unsigned)h;
   int n = 0;
   while (n < rem) {
-    const uint64_t x = ld64u(pp + n) ^ ld64u(tp + n);
+    const uint64_t x = ld64u(pp + (unsigned)n) ^ ld64u(tp + (unsigned)n);
     ++iters;
     if (x) {
       n += (int)(__builtin_ctzll(x) >> 3);
@@ -137,23 +314,71 @@ __device__ __forceinline__ int extend_lcp(const uint8_t* P, const uint8_t* T, in
   return min(n, rem);
 }
 
-template <bool BASE>
-__device__ __forceinline__ RowMeta get_meta(const KParams& kp, const Shared& sh, const RowMeta* base_meta, int dir,
-                                            int comp, int score) {
-  if (score < 0) return RowMeta{1, 0};
-  if (BASE) return base_meta[score * NCOMP + comp];
-  return sh.bi_meta[dir][comp][score & (kp.ring - 1)];
+// ---- sequences staged in LDS: forward bytes only; the reverse aligner reads the same bytes from
+// the far end (its byte order is mirrored, so leading-zero bytes of the XOR count the matches).
+__device__ __forceinline__ uint64_t lds_ld64(const uint8_t* seq, int addr) {
+  const unsigned* w = reinterpret_cast<const unsigned*>(seq + (addr & ~3));
+  const unsigned d0 = w[0], d1 = w[1], d2 = w[2];
+  const unsigned sh = (unsigned)addr & 3u;
+  const unsigned lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+  const unsigned hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// XOR of the next 8 pattern/text bytes at (v, h) of direction `dir`, and the matching-byte count
+template <int DIR>
+__device__ __forceinline__ uint64_t lds_probe(const uint8_t* seq, const SubCtx& cx, int v, int h) {
+  if (DIR == 0) return lds_ld64(seq, cx.p_off + v) ^ lds_ld64(seq, cx.t_off + h);
+  return lds_ld64(seq, cx.p_off + cx.plen - 8 - v) ^ lds_ld64(seq, cx.t_off + cx.tlen - 8 - h);
+}
+template <int DIR>
+__device__ __forceinline__ int probe_count(uint64_t x) {
+  if (x == 0) return 8;
+  return DIR == 0 ? (int)(__builtin_ctzll(x) >> 3) : (int)(__builtin_clzll(x) >> 3);
+}
+
+template <int DIR>
+__device__ __forceinline__ int extend_lcp_lds(const uint8_t* seq, const SubCtx& cx, int v, int h, unsigned& iters) {
+  const int rem = min(cx.plen - v, cx.tlen - h);
+  int n = 0;
+  while (n < rem) {
+    const uint64_t x = lds_probe<DIR>(seq, cx, v + n, h + n);
+    ++iters;
+    const int c = probe_count<DIR>(x);
+    n += c;
+    if (c < 8) break;
+  }
+  return min(n, rem);
+}
+
+// Copies the sub-problem's bytes into LDS (all threads; ends with a barrier).  Falls back to
+// global-memory reads when they do not fit the staging budget.
+__device__ __forceinline__ void stage_sequences(const KParams& kp, const Lds& lds, SubCtx& cx) {
+  const int pbytes = (cx.plen + 7) & ~7, tbytes = (cx.tlen + 7) & ~7;
+  cx.p_off = 8;
+  cx.t_off = 8 + pbytes + 16;
+  const int total = cx.t_off + tbytes + 16;
+  cx.seq_lds = total <= kp.lds_seq_bytes ? 1 : 0;
+  if (!cx.seq_lds) return;
+  uint64_t* dp = reinterpret_cast<uint64_t*>(lds.seq + cx.p_off);
+  uint64_t* dt = reinterpret_cast<uint64_t*>(lds.seq + cx.t_off);
+  for (int i = threadIdx.x; i < pbytes / 8; i += WG) dp[i] = ld64u(cx.P[0] + 8u * (unsigned)i);
+  for (int i = threadIdx.x; i < tbytes / 8; i += WG) dt[i] = ld64u(cx.T[0] + 8u * (unsigned)i);
+  __syncthreads();
 }
 
 template <bool BASE>
-__device__ __forceinline__ int32_t* row_ptr(const KParams& kp, int32_t* mem, int dir, int comp, int score) {
+__device__ __forceinline__ RowMeta get_meta(const KParams& kp, const Lds& lds, int dir, int comp, int score) {
+  if (score < 0) return ROW_EMPTY;
+  if (BASE) return uni(lds.base_meta[score * NCOMP + comp]);
+  return uni(lds.bi_meta[((dir) * NCOMP + (comp)) * kp.ring + (score & (kp.ring - 1))]);
+}
+
+template <bool BASE, typename OffT>
+__device__ __forceinline__ OffT* row_ptr(const KParams& kp, void* mem, int dir, int comp, int score) {
   if (score < 0) score = 0;  // null input rows are never dereferenced
-  if (BASE) return mem + ((size_t)score * NCOMP + comp) * (size_t)kp.wb_cap;
-  return mem + ((size_t)(dir * NCOMP + comp) * kp.ring + (size_t)(score & (kp.ring - 1))) * (size_t)kp.wcap;
-}
-
-__device__ __forceinline__ int32_t rd(const int32_t* p, const RowMeta& m, int k, int kmin) {
-  return (k >= m.lo && k <= m.hi) ? p[k - kmin] : OFF_NULL;
+  if (BASE) return (OffT*)mem + ((size_t)score * NCOMP + comp) * (size_t)kp.wb_cap;
+  return (OffT*)mem + ((size_t)(dir * NCOMP + comp) * kp.ring + (size_t)(score & (kp.ring - 1))) * (size_t)kp.wcap;
 }
 
 __device__ __forceinline__ void acc_reset(Acc& a) {
@@ -163,116 +388,294 @@ __device__ __forceinline__ void acc_reset(Acc& a) {
   a.oob = 0;
 }
 
-// One compute-next + extend step of one direction (A.3 + A.4).  Output rows are written
-// untrimmed; hull / max antidiagonal / oob land in `acc` (LDS atomics) and become the row
-// metadata in finalize_row() after the workgroup barrier.  Returns the number of cells.
+struct StepPlan {  // uniform description of one compute-next call
+  RowMeta src[7];  // Mx, O1, I1e, D1e, O2, I2e, D2e
+  int lo, hi;      // hull of the cells to compute (= predicted hull of the M row)
+};
+
+__device__ __forceinline__ void hull_add(RowMeta& h, const RowMeta& s, int dlo, int dhi) {
+  h.lo = min(h.lo, s.lo + dlo);  // empty rows ({K_BIG, -K_BIG}) drop out of min/max by themselves
+  h.hi = max(h.hi, s.hi + dhi);
+}
+
 template <bool P2, bool BASE>
-__device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, RowMeta* base_meta, const SubCtx& cx,
-                                           int32_t* mem, int dir, int score, Acc& acc, unsigned& ext_iters) {
+__device__ __forceinline__ void plan_step(const KParams& kp, const Lds& lds, int dir, int score, StepPlan& pl) {
+  const DevPenalties& pn = kp.pen;
+  pl.src[0] = get_meta<BASE>(kp, lds, dir, C_M, score - pn.x);
+  pl.src[1] = get_meta<BASE>(kp, lds, dir, C_M, score - pn.o1 - pn.e1);
+  pl.src[2] = get_meta<BASE>(kp, lds, dir, C_I1, score - pn.e1);
+  pl.src[3] = get_meta<BASE>(kp, lds, dir, C_D1, score - pn.e1);
+  pl.src[4] = pl.src[5] = pl.src[6] = ROW_EMPTY;
+  if (P2) {
+    pl.src[4] = get_meta<BASE>(kp, lds, dir, C_M, score - pn.o2 - pn.e2);
+    pl.src[5] = get_meta<BASE>(kp, lds, dir, C_I2, score - pn.e2);
+    pl.src[6] = get_meta<BASE>(kp, lds, dir, C_D2, score - pn.e2);
+  }
+  // Predicted hulls (exact unless some value goes out of bounds, which the step detects and then
+  // repairs in trim_pass): a cell of I (D) is non-NULL iff its left (right) source cell is, M iff
+  // any source is (A.3).  They are written to the row metadata right away -- the slot of the new
+  // score is not read by anyone during this step -- so nothing but lo/hi outlives the barrier.
+  RowMeta pred[NCOMP];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) pred[c] = ROW_EMPTY;
+  hull_add(pred[C_I1], pl.src[1], 1, 1);
+  hull_add(pred[C_I1], pl.src[2], 1, 1);
+  hull_add(pred[C_D1], pl.src[1], -1, -1);
+  hull_add(pred[C_D1], pl.src[3], -1, -1);
+  if (P2) {
+    hull_add(pred[C_I2], pl.src[4], 1, 1);
+    hull_add(pred[C_I2], pl.src[5], 1, 1);
+    hull_add(pred[C_D2], pl.src[4], -1, -1);
+    hull_add(pred[C_D2], pl.src[6], -1, -1);
+  }
+  hull_add(pred[C_M], pl.src[0], 0, 0);
+  hull_add(pred[C_M], pred[C_I1], 0, 0);
+  hull_add(pred[C_M], pred[C_D1], 0, 0);
+  if (P2) {
+    hull_add(pred[C_M], pred[C_I2], 0, 0);
+    hull_add(pred[C_M], pred[C_D2], 0, 0);
+  }
+  pl.lo = pred[C_M].lo;
+  pl.hi = pred[C_M].hi;
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) {
+    if (pred[c].lo > pred[c].hi) pred[c] = ROW_EMPTY;
+    if (BASE) lds.base_meta[score * NCOMP + c] = pred[c];
+    else lds.bi_meta[(dir * NCOMP + c) * kp.ring + (score & (kp.ring - 1))] = pred[c];
+  }
+}
+
+// One compute-next + extend step of one direction (A.3 + A.4).  Every lane owns VEC consecutive
+// diagonals (one 16-byte vector per row); the k-1 / k+1 neighbours come from element-shifted
+// vector loads.  Output rows are written untrimmed; max antidiagonal / oob land in `acc`.
+// Returns the number of cells.
+template <bool P2, bool BASE, typename OffT>
+__device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const Lds& lds, const SubCtx& cx, rsrc_t rs,
+                                           int dir, int score, const StepPlan& pl, Acc& acc, unsigned& ext_iters) {
+  constexpr int VEC = OffTraits<OffT>::VEC;
+  static_assert(VEC == 4, "lane vectors are 4 diagonals wide");
+  constexpr int WSPAN = 64 * VEC;
+  constexpr int ESZ = (int)sizeof(OffT);
   const DevPenalties& pn = kp.pen;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kmin = cx.kmin[dir];
-  const RowMeta mMx = get_meta<BASE>(kp, sh, base_meta, dir, C_M, score - pn.x);
-  const RowMeta mO1 = get_meta<BASE>(kp, sh, base_meta, dir, C_M, score - pn.o1 - pn.e1);
-  const RowMeta mI1 = get_meta<BASE>(kp, sh, base_meta, dir, C_I1, score - pn.e1);
-  const RowMeta mD1 = get_meta<BASE>(kp, sh, base_meta, dir, C_D1, score - pn.e1);
-  RowMeta mO2{1, 0}, mI2{1, 0}, mD2{1, 0};
-  if (P2) {
-    mO2 = get_meta<BASE>(kp, sh, base_meta, dir, C_M, score - pn.o2 - pn.e2);
-    mI2 = get_meta<BASE>(kp, sh, base_meta, dir, C_I2, score - pn.e2);
-    mD2 = get_meta<BASE>(kp, sh, base_meta, dir, C_D2, score - pn.e2);
-  }
-  int lo = INT_MAX, hi = INT_MIN;
-  if (!row_empty(mMx)) { lo = min(lo, mMx.lo); hi = max(hi, mMx.hi); }
-  if (!row_empty(mO1)) { lo = min(lo, mO1.lo - 1); hi = max(hi, mO1.hi + 1); }
-  if (!row_empty(mI1)) { lo = min(lo, mI1.lo + 1); hi = max(hi, mI1.hi + 1); }
-  if (!row_empty(mD1)) { lo = min(lo, mD1.lo - 1); hi = max(hi, mD1.hi - 1); }
-  if (P2) {
-    if (!row_empty(mO2)) { lo = min(lo, mO2.lo - 1); hi = max(hi, mO2.hi + 1); }
-    if (!row_empty(mI2)) { lo = min(lo, mI2.lo + 1); hi = max(hi, mI2.hi + 1); }
-    if (!row_empty(mD2)) { lo = min(lo, mD2.lo - 1); hi = max(hi, mD2.hi - 1); }
-  }
-  if (lo > hi) return 0;  // null step: acc stays reset -> all rows empty
-  if (lo - 1 < kmin || hi + 1 > kmin + cx.wcols - 1) {
+  const int lo = pl.lo, hi = pl.hi;
+  if (lo > hi) return 0;  // null step: all rows empty
+  if (lo - kmin < WSPAN + 1 || hi - kmin + WSPAN + VEC + 2 > cx.wcols) {  // whole-wave vector accesses stay in the row
     sh.error = ST_CAPACITY;
     return 0;
   }
-  const int32_t* pMx = row_ptr<BASE>(kp, mem, dir, C_M, score - pn.x);
-  const int32_t* pO1 = row_ptr<BASE>(kp, mem, dir, C_M, score - pn.o1 - pn.e1);
-  const int32_t* pI1 = row_ptr<BASE>(kp, mem, dir, C_I1, score - pn.e1);
-  const int32_t* pD1 = row_ptr<BASE>(kp, mem, dir, C_D1, score - pn.e1);
-  const int32_t* pO2 = P2 ? row_ptr<BASE>(kp, mem, dir, C_M, score - pn.o2 - pn.e2) : nullptr;
-  const int32_t* pI2 = P2 ? row_ptr<BASE>(kp, mem, dir, C_I2, score - pn.e2) : nullptr;
-  const int32_t* pD2 = P2 ? row_ptr<BASE>(kp, mem, dir, C_D2, score - pn.e2) : nullptr;
-  int32_t* oM = row_ptr<BASE>(kp, mem, dir, C_M, score);
-  int32_t* oI1 = row_ptr<BASE>(kp, mem, dir, C_I1, score);
-  int32_t* oD1 = row_ptr<BASE>(kp, mem, dir, C_D1, score);
-  int32_t* oI2 = P2 ? row_ptr<BASE>(kp, mem, dir, C_I2, score) : nullptr;
-  int32_t* oD2 = P2 ? row_ptr<BASE>(kp, mem, dir, C_D2, score) : nullptr;
-  const uint8_t* Pp = cx.P[dir];
-  const uint8_t* Tp = cx.T[dir];
+  const int sMx = row_off<BASE, OffT>(kp, dir, C_M, score - pn.x);
+  const int sO1 = row_off<BASE, OffT>(kp, dir, C_M, score - pn.o1 - pn.e1);
+  const int sI1 = row_off<BASE, OffT>(kp, dir, C_I1, score - pn.e1);
+  const int sD1 = row_off<BASE, OffT>(kp, dir, C_D1, score - pn.e1);
+  const int sO2 = P2 ? row_off<BASE, OffT>(kp, dir, C_M, score - pn.o2 - pn.e2) : 0;
+  const int sI2 = P2 ? row_off<BASE, OffT>(kp, dir, C_I2, score - pn.e2) : 0;
+  const int sD2 = P2 ? row_off<BASE, OffT>(kp, dir, C_D2, score - pn.e2) : 0;
+  const int tM = row_off<BASE, OffT>(kp, dir, C_M, score);
+  const int tI1 = row_off<BASE, OffT>(kp, dir, C_I1, score);
+  const int tD1 = row_off<BASE, OffT>(kp, dir, C_D1, score);
+  const int tI2 = P2 ? row_off<BASE, OffT>(kp, dir, C_I2, score) : 0;
+  const int tD2 = P2 ? row_off<BASE, OffT>(kp, dir, C_D2, score) : 0;
+  const gseq_t Pp = cx.P[dir];
+  const gseq_t Tp = cx.T[dir];
   const int plen = cx.plen, tlen = cx.tlen;
   const int colLo = lo - kmin, colHi = hi - kmin;
-  int wlo[NCOMP], whi[NCOMP];
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c) { wlo[c] = INT_MAX; whi[c] = INT_MIN; }
   int lane_maxak = 0;
   bool lane_oob = false;
-  for (int cb = (colLo & ~63) + 64 * wave; cb <= colHi; cb += WG) {
-    const int col = cb + lane;
-    const int k = col + kmin;
-    const bool act = col >= colLo && col <= colHi;
-    int32_t m = OFF_NULL, ins1 = OFF_NULL, del1 = OFF_NULL, ins2 = OFF_NULL, del2 = OFF_NULL;
-    if (act) {
-      const int32_t mx = rd(pMx, mMx, k, kmin);
-      const int32_t o1l = rd(pO1, mO1, k - 1, kmin), o1r = rd(pO1, mO1, k + 1, kmin);
-      const int32_t i1e = rd(pI1, mI1, k - 1, kmin), d1e = rd(pD1, mD1, k + 1, kmin);
-      ins1 = max(o1l, i1e) + 1;
-      del1 = max(o1r, d1e);
-      int32_t ins = ins1, del = del1;
-      if (P2) {
-        const int32_t o2l = rd(pO2, mO2, k - 1, kmin), o2r = rd(pO2, mO2, k + 1, kmin);
-        const int32_t i2e = rd(pI2, mI2, k - 1, kmin), d2e = rd(pD2, mD2, k + 1, kmin);
-        ins2 = max(o2l, i2e) + 1;
-        del2 = max(o2r, d2e);
-        ins = max(ins1, ins2);
-        del = max(del1, del2);
-      }
-      m = max(del, max(mx + 1, ins));
-      if ((uint32_t)m > (uint32_t)tlen || (uint32_t)(m - k) > (uint32_t)plen) {
-        lane_oob |= (m > NULLISH);
-        m = OFF_NULL;
-      }
-      if (m >= 0) {
-        m += extend_lcp(Pp, Tp, m - k, m, plen, tlen, ext_iters);
-        lane_maxak = max(lane_maxak, 2 * m - k);
-      }
-      oM[col] = m;
-      oI1[col] = ins1;
-      oD1[col] = del1;
-      if (P2) { oI2[col] = ins2; oD2[col] = del2; }
-    }
-    // trimming (A.3): first / last in-bounds diagonal per component, via ballots
-    auto inb = [&](int32_t v) { return (uint32_t)v <= (uint32_t)tlen && (uint32_t)(v - k) <= (uint32_t)plen; };
-    const bool bI1 = act && inb(ins1), bD1 = act && inb(del1);
-    const bool bI2 = P2 && act && inb(ins2), bD2 = P2 && act && inb(del2);
-    lane_oob |= act && ((!bI1 && ins1 > NULLISH) || (!bD1 && del1 > NULLISH));
-    if (P2) lane_oob |= act && ((!bI2 && ins2 > NULLISH) || (!bD2 && del2 > NULLISH));
-    const uint64_t masks[NCOMP] = {__ballot(act && m >= 0), __ballot(bI1), __ballot(bI2), __ballot(bD1), __ballot(bD2)};
+  for (int cb = (colLo & ~(WSPAN - 1)) + WSPAN * wave; cb <= colHi; cb += WSPAN * (WG / 64)) {
+    const int c0 = cb + lane * VEC;
+    const int k0 = c0 + kmin;
+    const int voff = (c0 - 1) * ESZ;  // byte offset of diagonal k0-1; shifts are immediates
+    // wave-uniform: does this wave's span (with its +-1 halo) lie inside every present source?
+    const int sl = cb + kmin - 1, sr = cb + kmin + WSPAN;
+    bool interior = true;
 #pragma unroll
-    for (int c = 0; c < NCOMP; ++c) {
-      if (!P2 && (c == C_I2 || c == C_D2)) continue;
-      if (masks[c]) {
-        wlo[c] = min(wlo[c], cb + (int)__builtin_ctzll(masks[c]));
-        whi[c] = max(whi[c], cb + 63 - (int)__builtin_clzll(masks[c]));
+    for (int r = 0; r < 7; ++r) {
+      if (!P2 && r >= 4) break;
+      interior = interior && pl.src[r].lo <= sl && sr <= pl.src[r].hi;  // (an empty row fails: lo > hi)
+    }
+    // All row loads are issued back to back with no control flow in between (absent rows read a
+    // valid dummy row), so the wave waits for memory once; unpack / mask afterwards.
+    const unsigned long long tc0 = PROF_NOW();
+    RawVec<OffT> rMx, rO1l, rO1r, rI1, rD1, rO2l, rO2r, rI2, rD2;
+    rMx = buf_load_raw<OffT>(rs, voff + ESZ, sMx);
+    rO1l = buf_load_raw<OffT>(rs, voff, sO1);
+    rO1r = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sO1);
+    rI1 = buf_load_raw<OffT>(rs, voff, sI1);
+    rD1 = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sD1);
+    if (P2) {
+      rO2l = buf_load_raw<OffT>(rs, voff, sO2);
+      rO2r = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sO2);
+      rI2 = buf_load_raw<OffT>(rs, voff, sI2);
+      rD2 = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sD2);
+    }
+    PROF_DRAIN();
+    PROF_ADD_L(STAT_T_CR_LOAD, tc0);
+    const unsigned long long tc1 = PROF_NOW();
+    int32_t vMx[VEC], vO1l[VEC], vO1r[VEC], vI1[VEC], vD1[VEC], vO2l[VEC], vO2r[VEC], vI2[VEC], vD2[VEC];
+    unpack_raw<OffT>(rMx, vMx);
+    unpack_raw<OffT>(rO1l, vO1l);
+    unpack_raw<OffT>(rO1r, vO1r);
+    unpack_raw<OffT>(rI1, vI1);
+    unpack_raw<OffT>(rD1, vD1);
+    if (P2) {
+      unpack_raw<OffT>(rO2l, vO2l);
+      unpack_raw<OffT>(rO2r, vO2r);
+      unpack_raw<OffT>(rI2, vI2);
+      unpack_raw<OffT>(rD2, vD2);
+    }
+    if (!interior) {  // edge waves (or a source row absent/narrower): mask by each row's own range
+      auto mask = [&](const RowMeta& mm, int shift, int32_t (&v)[VEC]) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const int kk = k0 + shift + j;
+          v[j] = (kk >= mm.lo && kk <= mm.hi) ? v[j] : OFF_NULL;
+        }
+      };
+      mask(pl.src[0], 0, vMx);
+      mask(pl.src[1], -1, vO1l);
+      mask(pl.src[1], +1, vO1r);
+      mask(pl.src[2], -1, vI1);
+      mask(pl.src[3], +1, vD1);
+      if (P2) {
+        mask(pl.src[4], -1, vO2l);
+        mask(pl.src[4], +1, vO2r);
+        mask(pl.src[5], -1, vI2);
+        mask(pl.src[6], +1, vD2);
       }
     }
+    int32_t m[VEC], ins1[VEC], del1[VEC], ins2[VEC], del2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int k = k0 + j;
+      ins1[j] = max(vO1l[j], vI1[j]) + 1;
+      del1[j] = max(vO1r[j], vD1[j]);
+      int32_t ins = ins1[j], del = del1[j];
+      if (P2) {
+        ins2[j] = max(vO2l[j], vI2[j]) + 1;
+        del2[j] = max(vO2r[j], vD2[j]);
+        ins = max(ins, ins2[j]);
+        del = max(del, del2[j]);
+      } else {
+        ins2[j] = del2[j] = OFF_NULL;
+      }
+      int32_t mm = max(del, max(vMx[j] + 1, ins));
+      // every value is <= mm, so nothing is out of bounds high unless mm is; low (v > plen) is per value
+      // in-bounds <=> 0 <= value <= hmax.  mm is the max of the cell's five values, so "some
+      // non-NULL value of this cell is out of bounds" <=> mm > hmax (any negative is a NULL(+n)).
+      const int hmax = max(min(tlen, plen + k), -1);
+      lane_oob |= mm > hmax;
+      m[j] = (mm > hmax || mm < 0) ? OFF_NULL : mm;
+    }
+    buf_store_vec<OffT>(rs, voff + ESZ, tI1, ins1, tlen);
+    buf_store_vec<OffT>(rs, voff + ESZ, tD1, del1, tlen);
+    if (P2) {
+      buf_store_vec<OffT>(rs, voff + ESZ, tI2, ins2, tlen);
+      buf_store_vec<OffT>(rs, voff + ESZ, tD2, del2, tlen);
+    }
+    PROF_DRAIN();
+    PROF_ADD_L(STAT_T_CR_ALU, tc1);
+    const unsigned long long tc2 = PROF_NOW();
+    // extend (A.4): the first 8-byte probe of all four cells is issued together (invalid cells
+    // probe offset 0, always readable), then the rare long runs continue in a loop
+    int rr[VEC], vv[VEC], hh[VEC];
+    uint64_t xx[VEC];
+    const bool in_lds = cx.seq_lds != 0;
+    const uint8_t* seq = lds.seq;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const bool ok = m[j] >= 0;
+      vv[j] = ok ? m[j] - (k0 + j) : 0;
+      hh[j] = ok ? m[j] : 0;
+      rr[j] = ok ? min(plen - vv[j], tlen - hh[j]) : 0;
+    }
+    // uniform branches hoisted out of the per-cell code so the four probes stay back to back
+    if (in_lds) {
+      if (dir == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) xx[j] = lds_probe<0>(seq, cx, vv[j], hh[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) xx[j] = lds_probe<1>(seq, cx, vv[j], hh[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) xx[j] = ld64u(Pp + (unsigned)vv[j]) ^ ld64u(Tp + (unsigned)hh[j]);
+    }
+    int cont = 0;
+    const bool mirrored = in_lds && dir == 1;  // LDS holds forward bytes: the reverse aligner counts from the top
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      int n = mirrored ? probe_count<1>(xx[j]) : probe_count<0>(xx[j]);
+      cont |= (n == 8 && rr[j] > 8) ? (1 << j) : 0;
+      n = min(n, rr[j]);
+      m[j] += n;  // rr == 0 for NULL cells: unchanged
+    }
+    ext_iters += VEC;
+    if (cont) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (cont & (1 << j)) {
+          const int v = m[j] - (k0 + j), h = m[j];
+          if (in_lds) m[j] += dir == 0 ? extend_lcp_lds<0>(seq, cx, v, h, ext_iters) : extend_lcp_lds<1>(seq, cx, v, h, ext_iters);
+          else m[j] += extend_lcp(Pp, Tp, v, h, plen, tlen, ext_iters);
+        }
+      }
+    }
+    PROF_DRAIN();
+    PROF_ADD_L(STAT_T_CR_EXTEND, tc2);
+    const unsigned long long tc3 = PROF_NOW();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+      if (m[j] >= 0) lane_maxak = max(lane_maxak, 2 * m[j] - (k0 + j));
+    buf_store_vec<OffT>(rs, voff + ESZ, tM, m, tlen);
+    PROF_DRAIN();
+    PROF_ADD_L(STAT_T_CR_STORE, tc3);
   }
+  const unsigned long long tc4 = PROF_NOW();
   const int wmax = wave_max_i32(lane_maxak);
   const bool woob = __any(lane_oob);
   if (lane == 0) {
     atomicMax(&acc.maxak, wmax);
     if (woob) acc.oob = 1;
+  }
+  PROF_ADD_L(STAT_T_CR_REDUCE, tc4);
+  return hi - lo + 1;
+}
+
+// Rare path (some value went out of bounds): find the trimmed hulls (A.3 "trim ends") by
+// rescanning the rows just written.  Must run after the barrier that follows compute_row.
+template <bool P2, bool BASE, typename OffT>
+__device__ __forceinline__ void trim_pass(const KParams& kp, const SubCtx& cx, void* mem, int dir, int score,
+                                          int lo, int hi, Acc& acc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kmin = cx.kmin[dir];
+  const int plen = cx.plen, tlen = cx.tlen;
+  const int colLo = lo - kmin, colHi = hi - kmin;
+  int wlo[NCOMP], whi[NCOMP];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) { wlo[c] = INT_MAX; whi[c] = INT_MIN; }
+  for (int cb = (colLo & ~63) + 64 * wave; cb <= colHi; cb += WG) {
+    const int col = cb + lane;
+    const int k = col + kmin;
+    const bool act = col >= colLo && col <= colHi;
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      if (!P2 && (c == C_I2 || c == C_D2)) continue;
+      bool inb = false;
+      if (act) {
+        const int32_t v = off_load1<OffT>(row_ptr<BASE, OffT>(kp, mem, dir, c, score) + col);
+        inb = (uint32_t)v <= (uint32_t)tlen && (uint32_t)(v - k) <= (uint32_t)plen;
+      }
+      const uint64_t mask = __ballot(inb);
+      if (mask) {
+        wlo[c] = min(wlo[c], cb + (int)__builtin_ctzll(mask));
+        whi[c] = max(whi[c], cb + 63 - (int)__builtin_clzll(mask));
+      }
+    }
+  }
+  if (lane == 0) {
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c) {
       if (wlo[c] != INT_MAX) {
@@ -281,25 +684,27 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, RowMet
       }
     }
   }
-  return hi - lo + 1;
 }
 
-// after the barrier: every thread writes the same trimmed metadata (benign same-value stores)
+// after the barrier: every thread writes the same values (benign same-value stores).  The predicted
+// metadata is already in place; only a trimmed row (rare) is patched.
 template <bool BASE>
-__device__ __forceinline__ void finalize_row(const KParams& kp, Shared& sh, RowMeta* base_meta, const SubCtx& cx,
-                                             int dir, int score, const Acc& acc) {
-  const int kmin = cx.kmin[dir];
+__device__ __forceinline__ void finalize_row(const KParams& kp, const Lds& lds, const SubCtx& cx, int dir, int score,
+                                             const Acc& acc, bool trimmed) {
+  if (trimmed) {
+    const int kmin = cx.kmin[dir];
 #pragma unroll
-  for (int c = 0; c < NCOMP; ++c) {
-    RowMeta m{1, 0};
-    const int l = acc.hull_lo[c], h = acc.hull_hi[c];
-    if (l != INT_MAX) { m.lo = l + kmin; m.hi = h + kmin; }
-    if (BASE) base_meta[score * NCOMP + c] = m;
-    else sh.bi_meta[dir][c][score & (kp.ring - 1)] = m;
+    for (int c = 0; c < NCOMP; ++c) {
+      RowMeta m = ROW_EMPTY;
+      const int l = uni(acc.hull_lo[c]), h = uni(acc.hull_hi[c]);
+      if (l != INT_MAX) { m.lo = l + kmin; m.hi = h + kmin; }
+      if (BASE) lds.base_meta[score * NCOMP + c] = m;
+      else lds.bi_meta[(dir * NCOMP + c) * kp.ring + (score & (kp.ring - 1))] = m;
+    }
   }
   if (!BASE) {
-    sh.bi_A[dir][score & (kp.ring - 1)] = acc.maxak;
-    sh.bi_oob[dir][score & (kp.ring - 1)] = acc.oob;
+    lds.bi_A[(dir) * kp.ring + (score & (kp.ring - 1))] = uni(acc.maxak);
+    lds.bi_oob[(dir) * kp.ring + (score & (kp.ring - 1))] = uni(acc.oob);
   }
 }
 
@@ -316,42 +721,48 @@ __device__ __forceinline__ void emit_run(Emit& em, uint8_t op, int len) {
   uint8_t* p = em.cig + em.n;
   for (int i = threadIdx.x; i < len; i += WG) p[i] = op;
   em.n += len;
-  em.cnt[op_index(op)] += len;
+  em.cnt[0] += op == 'M' ? len : 0;
+  em.cnt[1] += op == 'X' ? len : 0;
+  em.cnt[2] += op == 'I' ? len : 0;
+  em.cnt[3] += op == 'D' ? len : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Base case: plain WFA with full history + backtrace (A.5), wavefront_bialign_base
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int bt_fetch(const KParams& kp, const RowMeta* base_meta, const int32_t* hist, int kmin,
+template <typename OffT>
+__device__ __forceinline__ int bt_fetch(const KParams& kp, const RowMeta* base_meta, const OffT* hist, int kmin,
                                         int max_score, int comp, int score, int k, int add, int type) {
   if (score < 0 || score > max_score) return -1;
   const RowMeta m = base_meta[score * NCOMP + comp];
   if (k < m.lo || k > m.hi) return -1;
-  const int32_t v = hist[((size_t)score * NCOMP + comp) * (size_t)kp.wb_cap + (k - kmin)];
+  const int32_t v = (int32_t)hist[((size_t)score * NCOMP + comp) * (size_t)kp.wb_cap + (k - kmin)];
   if (v < 0) return -1;
   return ((v + add) << 4) | type;
 }
 
 enum { BT_I1_OPEN = 1, BT_I1_EXT = 2, BT_I2_OPEN = 3, BT_I2_EXT = 4, BT_D1_OPEN = 5, BT_D1_EXT = 6, BT_D2_OPEN = 7, BT_D2_EXT = 8, BT_M = 9 };
 
-template <bool P2>
-__device__ int base_align(const KParams& kp, Shared& sh, RowMeta* base_meta, SubCtx cx, int32_t* hist, uint32_t* events,
+template <bool P2, typename OffT>
+__device__ int base_align(const KParams& kp, Shared& sh, const Lds& lds, SubCtx cx, void* hist_mem, rsrc_t hist_rs, uint32_t* events,
                           int cb, int ce, Emit& em, int& penalty_out, unsigned long long* lstats) {
   const DevPenalties& pn = kp.pen;
   const int tid = threadIdx.x, lane = tid & 63;
   const int plen = cx.plen, tlen = cx.tlen;
+  OffT* hist = (OffT*)hist_mem;
+  RowMeta* base_meta = lds.base_meta;
   const int kspan_lo = min(plen, kp.sb_cap), kspan_hi = min(tlen, kp.sb_cap);
-  cx.kmin[0] = -kspan_lo - 4;
-  cx.wcols = kspan_lo + kspan_hi + 9;
+  cx.kmin[0] = -kspan_lo - 4 - COL_PAD;
+  cx.wcols = kspan_lo + kspan_hi + 9 + 2 * COL_PAD;
   if (cx.wcols > kp.wb_cap) return ST_CAPACITY;
   const int kmin = cx.kmin[0];
   // score 0
-  for (int c = tid; c < NCOMP; c += WG) base_meta[c] = (c == cb) ? RowMeta{0, 0} : RowMeta{1, 0};
+  for (int c = tid; c < NCOMP; c += WG) base_meta[c] = (c == cb) ? RowMeta{0, 0} : ROW_EMPTY;
   if (tid == 0) {
     unsigned it = 0;
     int v0 = 0;
     if (cb == C_M) v0 = extend_lcp(cx.P[0], cx.T[0], 0, 0, plen, tlen, it);
-    hist[(size_t)cb * kp.wb_cap + (0 - kmin)] = v0;
+    hist[(size_t)cb * kp.wb_cap + (0 - kmin)] = (OffT)v0;
     acc_reset(sh.acc[0][0]);
     acc_reset(sh.acc[1][0]);
     acc_reset(sh.acc[2][0]);
@@ -362,25 +773,34 @@ __device__ int base_align(const KParams& kp, Shared& sh, RowMeta* base_meta, Sub
   unsigned ext_iters = 0;
   unsigned long long cells = 0;
   int pass = 0;
+  const unsigned long long tb0 = PROF_NOW();
   for (;;) {
     // termination (wavefront_termination_end2end): end component reaches (plen, tlen)
-    const RowMeta me = base_meta[score * NCOMP + ce];
+    const RowMeta me = uni(base_meta[score * NCOMP + ce]);
     if (k_end >= me.lo && k_end <= me.hi) {
-      const int32_t v = hist[((size_t)score * NCOMP + ce) * (size_t)kp.wb_cap + (k_end - kmin)];
+      const int32_t v = uni(off_load1<OffT>(hist + ((size_t)score * NCOMP + ce) * (size_t)kp.wb_cap + (k_end - kmin)));
       if (v >= tlen) break;
     }
     ++score;
     if (score > kp.sb_cap) return ST_CAPACITY;
     Acc& acc = sh.acc[pass % 3][0];
-    cells += compute_row<P2, true>(kp, sh, base_meta, cx, hist, 0, score, acc, ext_iters);
+    StepPlan pl;
+    plan_step<P2, true>(kp, lds, 0, score, pl);
+    cells += compute_row<P2, true, OffT>(kp, sh, lds, cx, hist_rs, 0, score, pl, acc, ext_iters);
     __syncthreads();
-    if (sh.error) return sh.error;
-    finalize_row<true>(kp, sh, base_meta, cx, 0, score, acc);
+    if (uni(sh.error)) return uni(sh.error);
+    const bool trim = uni(acc.oob) != 0;
+    if (trim) {
+      trim_pass<P2, true, OffT>(kp, cx, hist_mem, 0, score, pl.lo, pl.hi, acc);
+      __syncthreads();
+    }
+    finalize_row<true>(kp, lds, cx, 0, score, acc, trim);
     if (tid == 0) acc_reset(sh.acc[(pass + 2) % 3][0]);
     ++pass;
-    __syncthreads();  // base_meta lives in dynamic LDS shared by all waves: make it visible
   }
   penalty_out = score;
+  PROF_ADD(STAT_T_BASE_STEPS, tb0);
+  const unsigned long long tb1 = PROF_NOW();
   if (tid == 0) {
     lstats[STAT_CELLS] += cells;
     lstats[STAT_BASE] += 1;
@@ -484,15 +904,18 @@ __device__ int base_align(const KParams& kp, Shared& sh, RowMeta* base_meta, Sub
     if (lane == 0) { sh.nev = nev; sh.bt_total = total; if (err) sh.error = err; }
   }
   __syncthreads();
-  if (sh.error) return sh.error;
+  PROF_ADD(STAT_T_BACKTRACE, tb1);
+  const unsigned long long tb2 = PROF_NOW();
+  if (uni(sh.error)) return uni(sh.error);
   // ---- emission: events were produced end -> start
-  const int nev = sh.nev;
-  const uint8_t opc[4] = {'M', 'X', 'I', 'D'};
+  const int nev = uni(sh.nev);
   for (int e = nev - 1; e >= 0; --e) {
-    const uint32_t ev = events[e];
-    emit_run(em, opc[ev & 3u], (int)(ev >> 2));
+    const uint32_t ev = (uint32_t)uni((int)events[e]);
+    const uint32_t opi = ev & 3u;
+    emit_run(em, opi == 0 ? 'M' : opi == 1 ? 'X' : opi == 2 ? 'I' : 'D', (int)(ev >> 2));
   }
   __syncthreads();  // events / sh.nev are reused by the next base case
+  PROF_ADD(STAT_T_EMIT, tb2);
   return ST_OK;
 }
 
@@ -501,23 +924,26 @@ __device__ int base_align(const KParams& kp, Shared& sh, RowMeta* base_meta, Sub
 // ---------------------------------------------------------------------------------------------
 constexpr int BP_OK = 0, BP_END_REACHED = 100;
 
-template <bool P2>
-__device__ void bialign_overlap(const KParams& kp, Shared& sh, const SubCtx& cx, int32_t* ring_mem, int d0, int s0,
+template <bool P2, typename OffT>
+__device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds& lds, const SubCtx& cx, void* ring_mem, int d0, int s0,
                                 int s1, bool fwd, Breakpoint& bp, unsigned long long* lstats) {
+  constexpr int VEC = OffTraits<OffT>::VEC;
+  constexpr int WSPAN = 64 * VEC;
   const DevPenalties& pn = kp.pen;
   const int d1 = 1 - d0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rmask = kp.ring - 1;
   const int plen = cx.plen, tlen = cx.tlen, L = plen + tlen, D = tlen - plen;
   const int slot0 = s0 & rmask;
-  const int A0 = sh.bi_A[d0][slot0], oob0 = sh.bi_oob[d0][slot0];
+  const int A0 = uni(lds.bi_A[(d0) * kp.ring + (slot0)]), oob0 = uni(lds.bi_oob[(d0) * kp.ring + (slot0)]);
   const int kmin0 = cx.kmin[d0], kmin1 = cx.kmin[d1];
+  const int Cm = D - kmin0 - kmin1;  // col1 = Cm - col0, Cm == 63 (mod 64)
   // exact pre-filter: an overlap needs antidiag0 + antidiag1 >= plen + tlen on some diagonal;
   // every in-bounds cell of any component at score s is <= the (extended) M cell, so the rows'
   // max M antidiagonals bound it unless an out-of-bounds value was seen (oob).
   auto group_pass = [&](int si) {
     const int slot1 = si & rmask;
-    return oob0 || sh.bi_oob[d1][slot1] || (A0 + sh.bi_A[d1][slot1] >= L);
+    return oob0 || uni(lds.bi_oob[(d1) * kp.ring + (slot1)]) || (A0 + uni(lds.bi_A[(d1) * kp.ring + (slot1)]) >= L);
   };
   bool any = false;
   for (int i = 0; i < pn.scope; ++i) {
@@ -527,33 +953,42 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const SubCtx& cx,
     if (s0 + si - (P2 ? max(pn.o1, pn.o2) : pn.o1) < bp.score) { any = true; break; }
   }
   if (!any) return;
-  for (int i = tid; i < pn.scope * NCOMP; i += WG) sh.firstk[i] = INT_MAX;
+  for (int i = tid; i < pn.scope * NCOMP; i += WG) lds.firstk[i] = INT_MAX;
   __syncthreads();
   // stage 1: parallel scan of every candidate wavefront pair (superset of what the sequential
   // search visits: the best score only decreases within a call)
   auto scan = [&](int c, int i, int si) {
-    const RowMeta r0 = sh.bi_meta[d0][c][slot0], r1 = sh.bi_meta[d1][c][si & rmask];
+    const RowMeta r0 = uni(lds.bi_meta[((d0) * NCOMP + (c)) * kp.ring + (slot0)]), r1 = uni(lds.bi_meta[((d1) * NCOMP + (c)) * kp.ring + (si & rmask)]);
     if (row_empty(r0) || row_empty(r1)) return;
     const int a = max(r0.lo, D - r1.hi), b = min(r0.hi, D - r1.lo);
     if (a > b) return;
     if (tid == 0) lstats[STAT_OVERLAP] += 1;
-    const int32_t* p0 = row_ptr<false>(kp, ring_mem, d0, c, s0);
-    const int32_t* p1 = row_ptr<false>(kp, ring_mem, d1, c, si);
+    const OffT* p0 = row_ptr<false, OffT>(kp, ring_mem, d0, c, s0);
+    const OffT* p1 = row_ptr<false, OffT>(kp, ring_mem, d1, c, si);
     const int ca = a - kmin0, cbn = b - kmin0;
-    for (int cbase = (ca & ~63) + 64 * wave; cbase <= cbn; cbase += WG) {
-      const int col0 = cbase + lane;
-      const bool act = col0 >= ca && col0 <= cbn;
-      const int k0 = col0 + kmin0, k1 = D - k0;
-      const int32_t h0 = act ? p0[col0] : OFF_NULL;
-      const int32_t h1 = act ? p1[k1 - kmin1] : OFF_NULL;
-      bool cond = act && (h0 + h1 >= tlen);
-      if (c != C_M) {  // indel2indel skips out-of-bounds forward coordinates
-        const int kf = fwd ? k0 : k1, hf = fwd ? h0 : h1;
-        cond = cond && !((hf - kf) > plen || hf > tlen);
+    for (int cbase = (ca & ~(WSPAN - 1)) + WSPAN * wave; cbase <= cbn; cbase += WSPAN * (WG / 64)) {
+      const int c0 = cbase + lane * VEC;
+      int32_t v0[VEC], v1[VEC];
+      off_load_vec<OffT, VEC>(p0 + c0, v0);
+      off_load_vec<OffT, VEC>(p1 + (Cm - c0 - (VEC - 1)), v1);  // mirrored: v1[VEC-1-j] pairs with v0[j]
+      int first = VEC;
+#pragma unroll
+      for (int j = VEC - 1; j >= 0; --j) {
+        const int col0 = c0 + j;
+        const int k0 = col0 + kmin0, k1 = D - k0;
+        const int32_t h0 = v0[j], h1 = v1[VEC - 1 - j];
+        bool cond = col0 >= ca && col0 <= cbn && (h0 + h1 >= tlen);
+        if (c != C_M) {  // indel2indel skips out-of-bounds forward coordinates
+          const int kf = fwd ? k0 : k1, hf = fwd ? h0 : h1;
+          cond = cond && !((hf - kf) > plen || hf > tlen);
+        }
+        if (cond) first = j;
       }
-      const uint64_t mask = __ballot(cond);
+      const uint64_t mask = __ballot(first < VEC);
       if (mask) {
-        if (lane == 0) atomicMin(&sh.firstk[i * NCOMP + c], cbase + (int)__builtin_ctzll(mask) + kmin0);
+        const int src = (int)__builtin_ctzll(mask);
+        const int fj = __builtin_amdgcn_readlane(first, src);
+        if (lane == 0) atomicMin(&lds.firstk[i * NCOMP + c], cbase + src * VEC + fj + kmin0);
         break;
       }
     }
@@ -569,12 +1004,12 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const SubCtx& cx,
   __syncthreads();
   // stage 2: replay in WFA2's order (per i: D2, I2, D1, I1, M; first k ascending)
   auto apply = [&](int c, int i, int si, int gap_open) {
-    const int k0 = sh.firstk[i * NCOMP + c];
+    const int k0 = uni(lds.firstk[i * NCOMP + c]);
     if (k0 == INT_MAX) return;
     if (s0 + si - gap_open >= bp.score) return;
     const int k1 = D - k0;
-    const int32_t h0 = row_ptr<false>(kp, ring_mem, d0, c, s0)[k0 - kmin0];
-    const int32_t h1 = row_ptr<false>(kp, ring_mem, d1, c, si)[k1 - kmin1];
+    const int32_t h0 = uni(off_load1<OffT>(row_ptr<false, OffT>(kp, ring_mem, d0, c, s0) + (k0 - kmin0)));
+    const int32_t h1 = uni(off_load1<OffT>(row_ptr<false, OffT>(kp, ring_mem, d1, c, si) + (k1 - kmin1)));
     if (fwd) { bp.sf = s0; bp.sr = si; bp.kf = k0; bp.kr = k1; bp.off_f = h0; bp.off_r = h1; }
     else { bp.sf = si; bp.sr = s0; bp.kf = k1; bp.kr = k0; bp.off_f = h1; bp.off_r = h0; }
     bp.score = s0 + si - gap_open;
@@ -592,8 +1027,8 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const SubCtx& cx,
   __syncthreads();  // firstk is rewritten by the next call
 }
 
-template <bool P2>
-__device__ int find_breakpoint(const KParams& kp, Shared& sh, SubCtx cx, int32_t* ring_mem, int cb, int ce,
+template <bool P2, typename OffT>
+__device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds& lds, SubCtx cx, void* ring_mem, rsrc_t ring_rs, int cb, int ce,
                                int score_remaining, Breakpoint& bp, unsigned long long* lstats) {
   const DevPenalties& pn = kp.pen;
   const int tid = threadIdx.x;
@@ -602,42 +1037,46 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, SubCtx cx, int32_t
   // column spaces: forward kmin, reverse kmin mirrored on chunk boundaries (C == 63 mod 64)
   {
     long long bound = (long long)score_remaining + 2LL * pn.scope + 16;
+    // the diagonal range is also clipped to what a row can hold; a wavefront that outgrows it is
+    // detected in compute_row (ST_CAPACITY) and the pair is re-run by the host with wider rows
+    const long long half = (kp.wcap - 2 * COL_PAD - 9 - 64) / 2;
+    bound = min(bound, half);
     const int blo = (int)min((long long)plen, bound), bhi = (int)min((long long)tlen, bound);
-    const int need = -blo - 4;
+    const int need = -blo - 4 - COL_PAD;
     cx.kmin[0] = need;
     const int D = tlen - plen;
     const int c0 = D - need - need;
     const int adj = ((63 - c0) % 64 + 64) % 64;
     cx.kmin[1] = need - adj;
-    cx.wcols = blo + bhi + 9 + adj;
+    cx.wcols = blo + bhi + 9 + adj + 2 * COL_PAD;
     if (cx.wcols > kp.wcap) return ST_CAPACITY;
   }
   // score-0 wavefronts (wavefront_unialign_init by begin component)
   for (int i = tid; i < 2 * NCOMP; i += WG) {
     const int dir = i / NCOMP, c = i % NCOMP;
     const int begin = dir == 0 ? cb : ce;
-    sh.bi_meta[dir][c][0] = (c == begin) ? RowMeta{0, 0} : RowMeta{1, 0};
+    lds.bi_meta[((dir) * NCOMP + (c)) * kp.ring + (0)] = (c == begin) ? RowMeta{0, 0} : ROW_EMPTY;
   }
   if (tid == 0 || tid == 64) {
     const int dir = tid >> 6;
     const int begin = dir == 0 ? cb : ce;
     unsigned it = 0;
     int v0 = 0;
-    if (begin == C_M) v0 = extend_lcp(cx.P[dir], cx.T[dir], 0, 0, plen, tlen, it);
-    row_ptr<false>(kp, ring_mem, dir, begin, 0)[0 - cx.kmin[dir]] = v0;
+    if (begin == C_M) v0 = extend_lcp(dir ? cx.P[1] : cx.P[0], dir ? cx.T[1] : cx.T[0], 0, 0, plen, tlen, it);
+    row_ptr<false, OffT>(kp, ring_mem, dir, begin, 0)[0 - (dir ? cx.kmin[1] : cx.kmin[0])] = (OffT)v0;
     sh.ext0[dir] = v0;
-    sh.bi_A[dir][0] = (begin == C_M) ? 2 * v0 : 0;
-    sh.bi_oob[dir][0] = 0;
+    lds.bi_A[(dir) * kp.ring + (0)] = (begin == C_M) ? 2 * v0 : 0;
+    lds.bi_oob[(dir) * kp.ring + (0)] = 0;
     acc_reset(sh.acc[0][dir]);
     acc_reset(sh.acc[1][dir]);
     acc_reset(sh.acc[2][dir]);
   }
   __syncthreads();
-  if (cb == C_M && ce == C_M && plen == tlen && (sh.ext0[0] >= tlen || sh.ext0[1] >= tlen)) return BP_END_REACHED;
+  if (cb == C_M && ce == C_M && plen == tlen && (uni(sh.ext0[0]) >= tlen || uni(sh.ext0[1]) >= tlen)) return BP_END_REACHED;
   const int max_antidiagonal = plen + tlen - 1;
-  int sf = 0, sr = 0;      // official scores
-  int cf = 0, cr = 0;      // computed scores (may run one ahead: speculative row)
-  int fmax = sh.bi_A[0][0], rmax = sh.bi_A[1][0];
+  int sc[2] = {0, 0};    // official scores (forward, reverse)
+  int comp[2] = {0, 0};  // computed scores (may run one ahead: speculative row)
+  int fmax = uni(lds.bi_A[(0) * kp.ring + (0)]), rmax = uni(lds.bi_A[(1) * kp.ring + (0)]);
   bp.score = INT_MAX;
   unsigned ext_iters = 0;
   unsigned long long cells = 0;
@@ -645,50 +1084,77 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, SubCtx cx, int32_t
   const long long max_steps = ((long long)pn.o1 + pn.o2 + 2LL * (pn.e1 + pn.e2) + pn.x) * ((long long)plen + tlen + 4) + 1024;
   long long steps = 0;
   int rc = BP_OK;
-  // one fused pass: next forward row and next reverse row (whichever is missing)
-  auto ensure_computed = [&]() {
-    const bool needF = cf == sf, needR = cr == sr;
-    if (!needF && !needR) return;
-    Acc* a = sh.acc[pass % 3];
-    if (needF) cells += compute_row<P2, false>(kp, sh, nullptr, cx, ring_mem, 0, sf + 1, a[0], ext_iters);
-    if (needR) cells += compute_row<P2, false>(kp, sh, nullptr, cx, ring_mem, 1, sr + 1, a[1], ext_iters);
-    __syncthreads();
-    if (needF) { finalize_row<false>(kp, sh, nullptr, cx, 0, sf + 1, a[0]); cf = sf + 1; }
-    if (needR) { finalize_row<false>(kp, sh, nullptr, cx, 1, sr + 1, a[1]); cr = sr + 1; }
-    if (tid == 0) { acc_reset(sh.acc[(pass + 2) % 3][0]); acc_reset(sh.acc[(pass + 2) % 3][1]); }
-    ++pass;
-  };
-  bool last_fwd = false;
-  // phase 1: until the furthest points can collide
-  for (;;) {
-    if (fmax + rmax >= max_antidiagonal) break;
-    ensure_computed();
-    if (sh.error) { rc = sh.error; break; }
-    ++sf;
-    fmax = max(fmax, sh.bi_A[0][sf & rmask]);
-    last_fwd = true;
-    if (fmax + rmax >= max_antidiagonal) break;
-    ++sr;
-    rmax = max(rmax, sh.bi_A[1][sr & rmask]);
-    last_fwd = false;
-    if (++steps > max_steps) { rc = ST_MAX_STEPS; break; }
-  }
-  // phase 2: until no better overlap is possible
   const int gap_opening = P2 ? max(pn.o1, pn.o2) : pn.o1;
-  while (rc == BP_OK) {
-    ensure_computed();
-    if (sh.error) { rc = sh.error; break; }
-    if (last_fwd) {
-      const int min_sr = (sr > pn.scope - 1) ? sr - (pn.scope - 1) : 0;
-      if (sf + min_sr - gap_opening >= bp.score) break;
-      bialign_overlap<P2>(kp, sh, cx, ring_mem, 0, sf, sr, true, bp, lstats);
-      ++sr;
+  bool last_fwd = false;
+  int phase = 1;
+  // One loop for both phases (A.6).  Each iteration first makes sure the next forward and the next
+  // reverse wavefront exist (one fused pass, one barrier), then runs WFA2's bookkeeping for it.
+  for (;;) {
+    if (phase == 1 && fmax + rmax >= max_antidiagonal) phase = 2;
+    {
+      Acc* a = sh.acc[pass % 3];
+      int plo[2] = {1, 1}, phi[2] = {0, 0};
+      bool need[2];
+      const unsigned long long tp0 = PROF_NOW();
+#pragma unroll
+      for (int dir = 0; dir < 2; ++dir) {  // unrolled: every per-direction array keeps constant indices
+        need[dir] = comp[dir] == sc[dir];
+        if (need[dir]) {
+          StepPlan pl;
+          plan_step<P2, false>(kp, lds, dir, sc[dir] + 1, pl);
+          cells += compute_row<P2, false, OffT>(kp, sh, lds, cx, ring_rs, dir, sc[dir] + 1, pl, a[dir], ext_iters);
+          plo[dir] = pl.lo;
+          phi[dir] = pl.hi;
+        }
+      }
+      if (need[0] || need[1]) {
+        PROF_ADD(STAT_T_BI_COMPUTE, tp0);
+        PROF_INC(STAT_N_PASSES);
+        const unsigned long long tp1 = PROF_NOW();
+        __syncthreads();
+        PROF_ADD(STAT_T_BI_BARRIER, tp1);
+        const unsigned long long tp2 = PROF_NOW();
+        if (uni(sh.error)) { rc = uni(sh.error); break; }
+        const bool trim0 = need[0] && uni(a[0].oob) != 0, trim1 = need[1] && uni(a[1].oob) != 0;
+        if (trim0 || trim1) {
+          if (trim0) trim_pass<P2, false, OffT>(kp, cx, ring_mem, 0, sc[0] + 1, plo[0], phi[0], a[0]);
+          if (trim1) trim_pass<P2, false, OffT>(kp, cx, ring_mem, 1, sc[1] + 1, plo[1], phi[1], a[1]);
+          __syncthreads();
+        }
+        if (need[0]) { finalize_row<false>(kp, lds, cx, 0, sc[0] + 1, a[0], trim0); comp[0] = sc[0] + 1; }
+        if (need[1]) { finalize_row<false>(kp, lds, cx, 1, sc[1] + 1, a[1], trim1); comp[1] = sc[1] + 1; }
+        if (tid == 0) { acc_reset(sh.acc[(pass + 2) % 3][0]); acc_reset(sh.acc[(pass + 2) % 3][1]); }
+        ++pass;
+        PROF_ADD(STAT_T_BI_FINALIZE, tp2);
+      }
     }
-    const int min_sf = (sf > pn.scope - 1) ? sf - (pn.scope - 1) : 0;
-    if (min_sf + sr - gap_opening >= bp.score) break;
-    bialign_overlap<P2>(kp, sh, cx, ring_mem, 1, sr, sf, false, bp, lstats);
-    ++sf;
-    last_fwd = true;
+    if (phase == 1) {
+      // phase 1: until the furthest points can collide
+      ++sc[0];
+      fmax = max(fmax, uni(lds.bi_A[0 * kp.ring + (sc[0] & rmask)]));
+      last_fwd = true;
+      if (fmax + rmax >= max_antidiagonal) { phase = 2; continue; }
+      ++sc[1];
+      rmax = max(rmax, uni(lds.bi_A[1 * kp.ring + (sc[1] & rmask)]));
+      last_fwd = false;
+    } else {
+      // phase 2: until no better overlap is possible
+      if (last_fwd) {
+        const int min_sr = (sc[1] > pn.scope - 1) ? sc[1] - (pn.scope - 1) : 0;
+        if (sc[0] + min_sr - gap_opening >= bp.score) break;
+        const unsigned long long to0 = PROF_NOW();
+        bialign_overlap<P2, OffT>(kp, sh, lds, cx, ring_mem, 0, sc[0], sc[1], true, bp, lstats);
+        PROF_ADD(STAT_T_OVERLAP, to0);
+        ++sc[1];
+      }
+      const int min_sf = (sc[0] > pn.scope - 1) ? sc[0] - (pn.scope - 1) : 0;
+      if (min_sf + sc[1] - gap_opening >= bp.score) break;
+      const unsigned long long to1 = PROF_NOW();
+      bialign_overlap<P2, OffT>(kp, sh, lds, cx, ring_mem, 1, sc[1], sc[0], false, bp, lstats);
+      PROF_ADD(STAT_T_OVERLAP, to1);
+      ++sc[0];
+      last_fwd = true;
+    }
     if (++steps > max_steps) { rc = ST_MAX_STEPS; break; }
   }
   if (tid == 0) {
@@ -704,18 +1170,27 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, SubCtx cx, int32_t
 // ---------------------------------------------------------------------------------------------
 // The kernel: persistent workgroups, one pair at a time, DFS over the BiWFA recursion
 // ---------------------------------------------------------------------------------------------
-template <bool P2>
-__global__ __launch_bounds__(WG) void biwfa_align_kernel(KParams kp) {
+template <bool P2, typename OffT>
+__global__ __launch_bounds__(WG, 4) void biwfa_align_kernel(KParams kp) {
   __shared__ Shared sh;
   __shared__ unsigned long long lstats[STAT_N];
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-  RowMeta* base_meta = reinterpret_cast<RowMeta*>(dyn_smem);
+  Lds lds;
+  lds.bi_meta = reinterpret_cast<RowMeta*>(dyn_smem);
+  lds.bi_A = reinterpret_cast<int*>(lds.bi_meta + 2 * NCOMP * kp.ring);
+  lds.bi_oob = lds.bi_A + 2 * kp.ring;
+  lds.firstk = lds.bi_oob + 2 * kp.ring;
+  lds.base_meta = reinterpret_cast<RowMeta*>(dyn_smem);
+  lds.seq = dyn_smem + kp.lds_meta_bytes;
   const int tid = threadIdx.x;
   const DevPenalties& pn = kp.pen;
-  int32_t* ring_mem = kp.ring_mem + (size_t)blockIdx.x * kp.ring_slot_stride;
-  int32_t* hist = kp.hist_mem + (size_t)blockIdx.x * kp.hist_slot_stride;
+  void* ring_mem = (char*)kp.ring_mem + (size_t)blockIdx.x * kp.ring_slot_stride;
+  void* hist = (char*)kp.hist_mem + (size_t)blockIdx.x * kp.hist_slot_stride;
   uint32_t* events = kp.ev_mem + (size_t)blockIdx.x * kp.ev_slot_stride;
+  const rsrc_t ring_rs = make_rsrc(ring_mem, kp.ring_slot_stride);
+  const rsrc_t hist_rs = make_rsrc(hist, kp.hist_slot_stride);
   if (tid < STAT_N) lstats[tid] = 0;
+  if (tid < 5) sh.prof[tid] = 0;
   __syncthreads();
   for (;;) {
     if (tid == 0) {
@@ -723,7 +1198,7 @@ __global__ __launch_bounds__(WG) void biwfa_align_kernel(KParams kp) {
       sh.error = 0;
     }
     __syncthreads();
-    const long long pair = sh.cur_pair;
+    const long long pair = ((long long)uni((int)(sh.cur_pair >> 32)) << 32) | (unsigned)uni((int)sh.cur_pair);
     if (pair >= kp.npairs) break;
     const int qi = kp.pair_q[pair], ti = kp.pair_t[pair];
     const int qv = kp.pair_rc[pair] ? 2 : 0;
@@ -733,6 +1208,7 @@ __global__ __launch_bounds__(WG) void biwfa_align_kernel(KParams kp) {
     const uint8_t* Pr = kp.seq[qv + 1] + qoff;
     const uint8_t* Tf = kp.seq[0] + toff;
     const uint8_t* Tr = kp.seq[1] + toff;
+    const unsigned long long tt0 = PROF_NOW();
     Emit em;
     em.cig = kp.cigar + kp.cigar_off[pair];
     em.n = 0;
@@ -748,7 +1224,9 @@ __global__ __launch_bounds__(WG) void biwfa_align_kernel(KParams kp) {
     __syncthreads();
     bool top = true;
     while (sp > 0 && status == ST_OK) {
-      const Task t = sh.stack[sp - 1];
+      Task t = sh.stack[sp - 1];
+      t.pb = uni(t.pb); t.pe = uni(t.pe); t.tb = uni(t.tb); t.te = uni(t.te);
+      t.cb = uni(t.cb); t.ce = uni(t.ce); t.score_remaining = uni(t.score_remaining);
       --sp;
       __syncthreads();  // everyone has read the entry before it can be overwritten
       const int plen = t.pe - t.pb, tlen = t.te - t.tb;
@@ -766,22 +1244,23 @@ __global__ __launch_bounds__(WG) void biwfa_align_kernel(KParams kp) {
       SubCtx cx;
       cx.plen = plen;
       cx.tlen = tlen;
-      cx.P[0] = Pf + t.pb;
-      cx.T[0] = Tf + t.tb;
-      cx.P[1] = Pr + (plenT - t.pe);
-      cx.T[1] = Tr + (tlenT - t.te);
+      cx.P[0] = to_global(Pf + t.pb);
+      cx.T[0] = to_global(Tf + t.tb);
+      cx.P[1] = to_global(Pr + (plenT - t.pe));
+      cx.T[1] = to_global(Tr + (tlenT - t.te));
       cx.kmin[0] = cx.kmin[1] = 0;
       cx.wcols = 0;
+      stage_sequences(kp, lds, cx);
       bool do_base = t.score_remaining <= FALLBACK_MIN_SCORE;
       Breakpoint bp;
       if (!do_base) {
-        const int rc = find_breakpoint<P2>(kp, sh, cx, ring_mem, t.cb, t.ce, t.score_remaining, bp, lstats);
+        const int rc = find_breakpoint<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, t.cb, t.ce, t.score_remaining, bp, lstats);
         if (rc == BP_END_REACHED) do_base = true;  // wavefront_bialign_exception -> plain WFA
         else if (rc != BP_OK) { status = rc; break; }
       }
       if (do_base) {
         int pen_b = 0;
-        const int rc = base_align<P2>(kp, sh, base_meta, cx, hist, events, t.cb, t.ce, em, pen_b, lstats);
+        const int rc = base_align<P2, OffT>(kp, sh, lds, cx, hist, hist_rs, events, t.cb, t.ce, em, pen_b, lstats);
         if (rc != ST_OK) { status = rc; break; }
         if (top) penalty = pen_b;
         top = false;
@@ -812,6 +1291,7 @@ __global__ __launch_bounds__(WG) void biwfa_align_kernel(KParams kp) {
       r.q_end = em.cnt[0] + em.cnt[1] + em.cnt[3];
       r.t_end = em.cnt[0] + em.cnt[1] + em.cnt[2];
       kp.results[pair] = r;
+      PROF_ADD(STAT_T_TOTAL, tt0);
       if (status == ST_OK) {
         lstats[STAT_ALIGNED_BP] += (unsigned long long)plenT;
         lstats[STAT_PAIRS] += 1;
@@ -819,6 +1299,8 @@ __global__ __launch_bounds__(WG) void biwfa_align_kernel(KParams kp) {
     }
     __syncthreads();
   }
+  __syncthreads();
+  if (tid < 5) lstats[STAT_T_CR_LOAD + tid] = sh.prof[tid];
   __syncthreads();
   if (tid < STAT_N && lstats[tid]) atomicAdd(&kp.stats[tid], lstats[tid]);
 }

@@ -98,7 +98,7 @@ struct awv_engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   SeqSet seqs;
   // scratch arenas (per persistent workgroup)
-  DevBuf<int32_t> ring_mem, hist_mem;
+  DevBuf<uint8_t> ring_mem, hist_mem;
   DevBuf<uint32_t> ev_mem;
   // per-launch buffers
   DevBuf<int32_t> d_pair_q, d_pair_t, d_pair_rc;
@@ -202,7 +202,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   }
   int ring = 4;
   while (ring < dp.scope + 2) ring *= 2;
-  const int nslots_cfg = e->cfg.workgroups > 0 ? e->cfg.workgroups : 3 * e->num_cus;
+  const int nslots_cfg = e->cfg.workgroups > 0 ? e->cfg.workgroups : 4 * e->num_cus;
   const int64_t max_batch = e->cfg.max_batch_pairs > 0 ? e->cfg.max_batch_pairs : (int64_t)1 << 20;
   const uint64_t max_arena = e->cfg.max_arena_bytes > 0 ? (uint64_t)e->cfg.max_arena_bytes : (uint64_t)8 << 30;
   // base-case capacities: score_remaining <= 250 or both lengths <= 100
@@ -212,8 +212,12 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
                                            worst_case_penalty(dp, FALLBACK_MIN_LENGTH));
   if (sb > 4000) return fail(AWV_ERR_PENALTIES, "penalties too large for the base-case history");
   const int sb_cap = (int)sb;
-  const int wb_cap = ((2 * sb_cap + 9) + 63) & ~63;
-  const size_t dyn_lds = (size_t)(sb_cap + 1) * NCOMP * sizeof(RowMeta);
+  const int wb_cap = ((2 * sb_cap + 9 + 2 * COL_PAD) + 63) & ~63;
+  // dynamic LDS: metadata region (BiWFA ring metadata, aliased with the base-case table) + sequences
+  const size_t bi_bytes = (size_t)2 * NCOMP * ring * sizeof(RowMeta) + (size_t)4 * ring * sizeof(int) +
+                          (size_t)dp.scope * NCOMP * sizeof(int);
+  const size_t base_bytes = (size_t)(sb_cap + 1) * NCOMP * sizeof(RowMeta);
+  const size_t lds_meta = (std::max(bi_bytes, base_bytes) + 15) & ~(size_t)15;
 
   std::vector<int32_t> hq, ht, hrc;
   std::vector<uint64_t> hoff;
@@ -226,7 +230,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     // ---- carve a batch
     int64_t n = 0;
     uint64_t arena = 0;
-    int maxsum = 0;
+    int maxsum = 0, maxlen = 0;
     hq.clear(); ht.clear(); hrc.clear(); hoff.clear();
     while (first + n < npairs && n < max_batch) {
       const awv_pair& p = pairs[first + n];
@@ -239,12 +243,24 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       hoff.push_back(arena);
       arena += need;
       maxsum = std::max(maxsum, ql + tl);
+      maxlen = std::max(maxlen, std::max(ql, tl));
       ++n;
     }
-    const int wcap = ((maxsum + 9 + 64) + 63) & ~63;
+    int wcap = ((maxsum + 9 + 64 + 2 * COL_PAD) + 63) & ~63;
+    if (const char* env = getenv("AWV_WCAP_MAX")) wcap = std::min(wcap, std::max(2048, atoi(env)));  // experiment knob
     const int nslots = (int)std::min<int64_t>(nslots_cfg, n);
-    const size_t ring_stride = (size_t)2 * NCOMP * ring * wcap;
-    const size_t hist_stride = (size_t)(sb_cap + 1) * NCOMP * wb_cap;
+    // 16-bit wavefront rows whenever every offset fits (halves the HBM/L2 traffic of the rings)
+    // sequence staging: what the largest pair needs, within a 40 KB-per-workgroup LDS budget
+    // (4 workgroups per CU of 160 KB); sub-problems that do not fit read global memory instead
+    const size_t seq_need = (size_t)8 + (((size_t)maxlen + 7) & ~(size_t)7) * 2 + 16 + 16 + 16;
+    const size_t lds_budget = 40960 - 3584;
+    size_t lds_seq = lds_meta < lds_budget ? std::min(seq_need, lds_budget - lds_meta) : 0;
+    lds_seq &= ~(size_t)15;
+    const size_t dyn_lds = lds_meta + lds_seq;
+    const bool narrow = maxlen < 32760 && !(e->cfg.flags & AWV_F_FORCE_INT32);
+    const size_t esz = narrow ? 2 : 4;
+    const size_t ring_stride = (size_t)2 * NCOMP * ring * wcap * esz;
+    const size_t hist_stride = (size_t)(sb_cap + 1) * NCOMP * wb_cap * esz;
     const size_t ev_stride = (size_t)wcap;
     if (int rc = e->ring_mem.reserve(ring_stride * nslots)) return rc;
     if (int rc = e->hist_mem.reserve(hist_stride * nslots)) return rc;
@@ -282,6 +298,8 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     kp.wcap = wcap;
     kp.ring_mem = e->ring_mem.p;
     kp.ring_slot_stride = ring_stride;
+    kp.lds_meta_bytes = (int)lds_meta;
+    kp.lds_seq_bytes = (int)lds_seq;
     kp.sb_cap = sb_cap;
     kp.wb_cap = wb_cap;
     kp.hist_mem = e->hist_mem.p;
@@ -294,13 +312,15 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     kp.work_counter = e->d_counters.p;
     kp.stats = e->d_counters.p + 1;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    if (dp.two_piece) {
-      HIP_TRY(hipFuncSetAttribute((const void*)biwfa_align_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
-      hipLaunchKernelGGL(biwfa_align_kernel<true>, dim3(nslots), dim3(WG), dyn_lds, e->stream, kp);
-    } else {
-      HIP_TRY(hipFuncSetAttribute((const void*)biwfa_align_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
-      hipLaunchKernelGGL(biwfa_align_kernel<false>, dim3(nslots), dim3(WG), dyn_lds, e->stream, kp);
-    }
+    auto launch = [&](auto kern) -> int {
+      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+      hipLaunchKernelGGL(kern, dim3(nslots), dim3(WG), dyn_lds, e->stream, kp);
+      return AWV_OK;
+    };
+    int lrc;
+    if (dp.two_piece) lrc = narrow ? launch(biwfa_align_kernel<true, int16_t>) : launch(biwfa_align_kernel<true, int32_t>);
+    else lrc = narrow ? launch(biwfa_align_kernel<false, int16_t>) : launch(biwfa_align_kernel<false, int32_t>);
+    if (lrc != AWV_OK) return lrc;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     HIP_TRY(hipEventSynchronize(e->ev1));
@@ -343,6 +363,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   e->stats.aligned_bp = stat_tot[STAT_ALIGNED_BP];
   e->stats.pairs_completed = stat_tot[STAT_PAIRS];
   e->stats.scratch_bytes = e->ring_mem.bytes() + e->hist_mem.bytes() + e->ev_mem.bytes();
+  for (int i = 0; i < 14; ++i) e->stats.prof[i] = stat_tot[STAT_T_TOTAL + i];
   return AWV_OK;
 }
 

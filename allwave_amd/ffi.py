@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liballwave_hip.so")
+LIB_PATH = os.environ.get("AWV_HIP_LIB") or os.path.join(_HERE, "liballwave_hip.so")
 
 AWV_OK = 0
 AWV_ERR_NO_DEVICE = -1
@@ -46,7 +46,8 @@ class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
                 ("launches", C.c_uint64), ("cell_steps", C.c_uint64), ("extend_steps", C.c_uint64),
                 ("n_breakpoints", C.c_uint64), ("n_base", C.c_uint64), ("overlap_scans", C.c_uint64),
-                ("aligned_bp", C.c_uint64), ("pairs_completed", C.c_uint64), ("scratch_bytes", C.c_uint64)]
+                ("aligned_bp", C.c_uint64), ("pairs_completed", C.c_uint64), ("scratch_bytes", C.c_uint64),
+                ("prof", C.c_uint64 * 14)]
 
 
 PAIR_DTYPE = np.dtype([("q_idx", "<i4"), ("t_idx", "<i4"), ("q_revcomp", "<i4")])

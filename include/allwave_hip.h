@@ -74,6 +74,7 @@ typedef struct {
 } awv_engine_config;
 
 #define AWV_F_KEEP_ON_DEVICE 1 /* do not copy CIGARs back (kernel-only measurements) */
+#define AWV_F_FORCE_INT32 2    /* always use 32-bit wavefront rows (default: 16-bit when lengths < 32760) */
 
 /* penalties as allwave passes them to lib_wfa2 (src/alignment.rs:263-289) */
 typedef struct {
@@ -123,6 +124,11 @@ typedef struct {
   uint64_t aligned_bp;      /* sum of query lengths of completed pairs */
   uint64_t pairs_completed;
   uint64_t scratch_bytes;   /* device scratch currently allocated */
+  /* shader-clock cycles summed over workgroups; only filled by the -DAWV_PROF diagnostic build:
+   * [0] total, [1] step compute, [2] step barrier wait, [3] step finalize, [4] overlap search,
+   * [5] base-case steps, [6] backtrace, [7] CIGAR emission, [8] number of fused step passes,
+   * [9..13] inside the step: row loads, DP arithmetic, extend, stores, reductions */
+  uint64_t prof[14];
 } awv_stats;
 
 int awv_abi_version(void);

@@ -30,7 +30,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(ffi.Penalties) == 28
     assert ffi.PAIR_DTYPE.itemsize == 12
     assert ffi.RESULT_DTYPE.itemsize == 48
-    assert C.sizeof(ffi.Stats) == 8 * 12
+    assert C.sizeof(ffi.Stats) == 8 * 26
 
 
 def test_code_object_is_gfx950(hip_lib):
