@@ -51,7 +51,8 @@ def build_host(force=False, verbose=False):
         return None
     if force or _newer(HOST_LIB, srcs + [os.path.join(ROOT, "include", "allwave_hip.h")]):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
-               "-I" + host_dir, "-o", HOST_LIB] + cpps + ["-ldl"]
+               "-I" + host_dir, "-o", HOST_LIB] + cpps + ["-L" + PKG, "-lallwave_hip", "-Wl,-rpath,$ORIGIN",
+                                                           "-Wl,-rpath-link,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -25,7 +25,10 @@
 
 namespace awv {
 
-constexpr int WG = 256;
+#ifndef AWV_WG
+#define AWV_WG 64
+#endif
+constexpr int WG = AWV_WG;  // threads per workgroup = per sequence pair (64, 128 or 256)
 constexpr int MAX_RING = 128;
 constexpr int NCOMP = 5;
 constexpr int32_t OFF_NULL = INT32_MIN / 2;
@@ -34,7 +37,7 @@ constexpr int32_t NULL16 = -16384;            // NULL as stored in 16-bit rows (
 enum { C_M = 0, C_I1 = 1, C_I2 = 2, C_D1 = 3, C_D2 = 4 };
 constexpr int FALLBACK_MIN_SCORE = 250;
 constexpr int FALLBACK_MIN_LENGTH = 100;
-constexpr int STACK_CAP = 96;
+constexpr int STACK_CAP = 48;
 constexpr int COL_PAD = 576;  // columns of slack either side of a row: whole-wave vector loads stay inside it
 
 // per-pair status (allwave_hip.h AWV_ST_*)
@@ -111,12 +114,27 @@ struct Breakpoint { int score, sf, sr, kf, kr, off_f, off_r, comp; };
 //   [ bi_meta[2][NCOMP][ring] | bi_A[2][ring] | bi_oob[2][ring] | firstk[scope*NCOMP] ]  (BiWFA search)
 //   aliased with base_meta[(sb_cap+1)*NCOMP]                                             (base case)
 //   [ seq: the sub-problem's pattern and text bytes, 8-byte padded ]
+struct RowMeta16 { int16_t lo, hi; };  // base-case rows: |k| <= sb_cap + padding fits 16 bits; empty = {1, 0}
+struct BaseMetaRef {                   // proxy so base_meta[i] reads/writes RowMeta transparently
+  RowMeta16* p;
+  __device__ __forceinline__ operator RowMeta() const {
+    const RowMeta16 m = *p;
+    return m.lo > m.hi ? ROW_EMPTY : RowMeta{m.lo, m.hi};
+  }
+  __device__ __forceinline__ void operator=(const RowMeta& m) const {
+    *p = m.lo > m.hi ? RowMeta16{1, 0} : RowMeta16{(int16_t)m.lo, (int16_t)m.hi};
+  }
+};
+struct BaseMeta {
+  RowMeta16* p;
+  __device__ __forceinline__ BaseMetaRef operator[](int i) const { return BaseMetaRef{p + i}; }
+};
 struct Lds {
   RowMeta* bi_meta;
   int* bi_A;
   int* bi_oob;
   int* firstk;
-  RowMeta* base_meta;
+  BaseMeta base_meta;
   uint8_t* seq;
 };
 struct Shared {
@@ -370,7 +388,7 @@ __device__ __forceinline__ void stage_sequences(const KParams& kp, const Lds& ld
 template <bool BASE>
 __device__ __forceinline__ RowMeta get_meta(const KParams& kp, const Lds& lds, int dir, int comp, int score) {
   if (score < 0) return ROW_EMPTY;
-  if (BASE) return uni(lds.base_meta[score * NCOMP + comp]);
+  if (BASE) return uni((RowMeta)lds.base_meta[score * NCOMP + comp]);
   return uni(lds.bi_meta[((dir) * NCOMP + (comp)) * kp.ring + (score & (kp.ring - 1))]);
 }
 
@@ -731,7 +749,7 @@ __device__ __forceinline__ void emit_run(Emit& em, uint8_t op, int len) {
 // Base case: plain WFA with full history + backtrace (A.5), wavefront_bialign_base
 // ---------------------------------------------------------------------------------------------
 template <typename OffT>
-__device__ __forceinline__ int bt_fetch(const KParams& kp, const RowMeta* base_meta, const OffT* hist, int kmin,
+__device__ __forceinline__ int bt_fetch(const KParams& kp, const BaseMeta& base_meta, const OffT* hist, int kmin,
                                         int max_score, int comp, int score, int k, int add, int type) {
   if (score < 0 || score > max_score) return -1;
   const RowMeta m = base_meta[score * NCOMP + comp];
@@ -750,7 +768,7 @@ __device__ int base_align(const KParams& kp, Shared& sh, const Lds& lds, SubCtx 
   const int tid = threadIdx.x, lane = tid & 63;
   const int plen = cx.plen, tlen = cx.tlen;
   OffT* hist = (OffT*)hist_mem;
-  RowMeta* base_meta = lds.base_meta;
+  const BaseMeta base_meta = lds.base_meta;
   const int kspan_lo = min(plen, kp.sb_cap), kspan_hi = min(tlen, kp.sb_cap);
   cx.kmin[0] = -kspan_lo - 4 - COL_PAD;
   cx.wcols = kspan_lo + kspan_hi + 9 + 2 * COL_PAD;
@@ -776,7 +794,7 @@ __device__ int base_align(const KParams& kp, Shared& sh, const Lds& lds, SubCtx 
   const unsigned long long tb0 = PROF_NOW();
   for (;;) {
     // termination (wavefront_termination_end2end): end component reaches (plen, tlen)
-    const RowMeta me = uni(base_meta[score * NCOMP + ce]);
+    const RowMeta me = uni((RowMeta)base_meta[score * NCOMP + ce]);
     if (k_end >= me.lo && k_end <= me.hi) {
       const int32_t v = uni(off_load1<OffT>(hist + ((size_t)score * NCOMP + ce) * (size_t)kp.wb_cap + (k_end - kmin)));
       if (v >= tlen) break;
@@ -1057,8 +1075,8 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds& lds, Su
     const int begin = dir == 0 ? cb : ce;
     lds.bi_meta[((dir) * NCOMP + (c)) * kp.ring + (0)] = (c == begin) ? RowMeta{0, 0} : ROW_EMPTY;
   }
-  if (tid == 0 || tid == 64) {
-    const int dir = tid >> 6;
+  if (tid == 0 || tid == (WG > 64 ? 64 : 1)) {
+    const int dir = tid ? 1 : 0;
     const int begin = dir == 0 ? cb : ce;
     unsigned it = 0;
     int v0 = 0;
@@ -1180,7 +1198,7 @@ __global__ __launch_bounds__(WG, 4) void biwfa_align_kernel(KParams kp) {
   lds.bi_A = reinterpret_cast<int*>(lds.bi_meta + 2 * NCOMP * kp.ring);
   lds.bi_oob = lds.bi_A + 2 * kp.ring;
   lds.firstk = lds.bi_oob + 2 * kp.ring;
-  lds.base_meta = reinterpret_cast<RowMeta*>(dyn_smem);
+  lds.base_meta = BaseMeta{reinterpret_cast<RowMeta16*>(dyn_smem)};
   lds.seq = dyn_smem + kp.lds_meta_bytes;
   const int tid = threadIdx.x;
   const DevPenalties& pn = kp.pen;

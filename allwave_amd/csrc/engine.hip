@@ -202,7 +202,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   }
   int ring = 4;
   while (ring < dp.scope + 2) ring *= 2;
-  const int nslots_cfg = e->cfg.workgroups > 0 ? e->cfg.workgroups : 4 * e->num_cus;
+  const int nslots_cfg = e->cfg.workgroups > 0 ? e->cfg.workgroups : (1024 / WG) * e->num_cus;
   const int64_t max_batch = e->cfg.max_batch_pairs > 0 ? e->cfg.max_batch_pairs : (int64_t)1 << 20;
   const uint64_t max_arena = e->cfg.max_arena_bytes > 0 ? (uint64_t)e->cfg.max_arena_bytes : (uint64_t)8 << 30;
   // base-case capacities: score_remaining <= 250 or both lengths <= 100
@@ -216,7 +216,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   // dynamic LDS: metadata region (BiWFA ring metadata, aliased with the base-case table) + sequences
   const size_t bi_bytes = (size_t)2 * NCOMP * ring * sizeof(RowMeta) + (size_t)4 * ring * sizeof(int) +
                           (size_t)dp.scope * NCOMP * sizeof(int);
-  const size_t base_bytes = (size_t)(sb_cap + 1) * NCOMP * sizeof(RowMeta);
+  const size_t base_bytes = (size_t)(sb_cap + 1) * NCOMP * sizeof(RowMeta16);
   const size_t lds_meta = (std::max(bi_bytes, base_bytes) + 15) & ~(size_t)15;
 
   std::vector<int32_t> hq, ht, hrc;
@@ -248,12 +248,12 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     }
     int wcap = ((maxsum + 9 + 64 + 2 * COL_PAD) + 63) & ~63;
     if (const char* env = getenv("AWV_WCAP_MAX")) wcap = std::min(wcap, std::max(2048, atoi(env)));  // experiment knob
-    const int nslots = (int)std::min<int64_t>(nslots_cfg, n);
+    int nslots = (int)std::min<int64_t>(nslots_cfg, n);
     // 16-bit wavefront rows whenever every offset fits (halves the HBM/L2 traffic of the rings)
     // sequence staging: what the largest pair needs, within a 40 KB-per-workgroup LDS budget
     // (4 workgroups per CU of 160 KB); sub-problems that do not fit read global memory instead
     const size_t seq_need = (size_t)8 + (((size_t)maxlen + 7) & ~(size_t)7) * 2 + 16 + 16 + 16;
-    const size_t lds_budget = 40960 - 3584;
+    const size_t lds_budget = (size_t)(160 * 1024 / (1024 / WG)) - 2560;  // 16 waves per CU
     size_t lds_seq = lds_meta < lds_budget ? std::min(seq_need, lds_budget - lds_meta) : 0;
     lds_seq &= ~(size_t)15;
     const size_t dyn_lds = lds_meta + lds_seq;
@@ -262,6 +262,12 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     const size_t ring_stride = (size_t)2 * NCOMP * ring * wcap * esz;
     const size_t hist_stride = (size_t)(sb_cap + 1) * NCOMP * wb_cap * esz;
     const size_t ev_stride = (size_t)wcap;
+    {  // keep the per-workgroup arenas inside the scratch budget (default 160 GiB of the 288 GB HBM)
+      const size_t budget = e->cfg.max_scratch_bytes > 0 ? (size_t)e->cfg.max_scratch_bytes : (size_t)160 << 30;
+      const size_t per_slot = ring_stride + hist_stride + ev_stride * sizeof(uint32_t);
+      const size_t fit = std::max<size_t>(1, budget / per_slot);
+      if ((size_t)nslots > fit) nslots = (int)fit;
+    }
     if (int rc = e->ring_mem.reserve(ring_stride * nslots)) return rc;
     if (int rc = e->hist_mem.reserve(hist_stride * nslots)) return rc;
     if (int rc = e->ev_mem.reserve(ev_stride * nslots)) return rc;

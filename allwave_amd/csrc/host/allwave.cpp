@@ -1,0 +1,396 @@
+// allwave.cpp -- host-side mirror of allwave's API over the C ABI (see allwave.hpp).
+#include "allwave.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <memory>
+#include <thread>
+
+namespace allwave {
+
+// ---- types.rs -------------------------------------------------------------------------------
+AlignmentParams AlignmentParams::edit_distance() {  // types.rs:62-73
+  AlignmentParams p;
+  p.match_score = 0;
+  p.mismatch_penalty = 1;
+  p.gap_open = 1;
+  p.gap_extend = 1;
+  p.gap2_open.reset();
+  p.gap2_extend.reset();
+  p.max_divergence.reset();
+  return p;
+}
+
+bool AlignmentParams::operator==(const AlignmentParams& o) const {
+  return match_score == o.match_score && mismatch_penalty == o.mismatch_penalty && gap_open == o.gap_open &&
+         gap_extend == o.gap_extend && gap2_open == o.gap2_open && gap2_extend == o.gap2_extend &&
+         max_divergence == o.max_divergence;
+}
+
+AlignmentMode alignment_mode_from_params(const AlignmentParams& p) {  // types.rs:107-116
+  if (p.gap2_open.has_value() && p.gap2_extend.has_value()) return AlignmentMode::TwoPieceAffine;
+  if (p.gap_open == p.gap_extend && p.gap_open == p.mismatch_penalty) return AlignmentMode::EditDistance;
+  return AlignmentMode::SinglePieceAffine;
+}
+
+awv_penalties to_penalties(const AlignmentParams& p) {  // alignment.rs:263-289
+  awv_penalties q{};
+  q.match = p.match_score;
+  q.mismatch = p.mismatch_penalty;
+  switch (alignment_mode_from_params(p)) {
+    case AlignmentMode::EditDistance:  // "edit" is gap-affine (x, x, x)
+      q.gap_open1 = p.mismatch_penalty;
+      q.gap_ext1 = p.mismatch_penalty;
+      break;
+    case AlignmentMode::SinglePieceAffine:
+      q.gap_open1 = p.gap_open;
+      q.gap_ext1 = p.gap_extend;
+      break;
+    case AlignmentMode::TwoPieceAffine:
+      q.gap_open1 = p.gap_open;
+      q.gap_ext1 = p.gap_extend;
+      q.gap_open2 = p.gap2_open.value_or(p.gap_open);
+      q.gap_ext2 = p.gap2_extend.value_or(p.gap_extend);
+      q.two_piece = 1;
+      break;
+  }
+  return q;
+}
+
+// ---- lib.rs ---------------------------------------------------------------------------------
+AlignmentParams parse_scores(const std::string& scores_str) {  // lib.rs:116-153
+  std::vector<int32_t> scores;
+  size_t pos = 0;
+  while (true) {
+    size_t comma = scores_str.find(',', pos);
+    std::string tok = scores_str.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+    size_t b = tok.find_first_not_of(" \t\n\r"), e = tok.find_last_not_of(" \t\n\r");
+    tok = b == std::string::npos ? "" : tok.substr(b, e - b + 1);
+    size_t used = 0;
+    long v = 0;
+    bool ok = !tok.empty();
+    if (ok) {
+      try { v = std::stol(tok, &used, 10); } catch (...) { ok = false; }
+      ok = ok && used == tok.size() && v >= INT32_MIN && v <= INT32_MAX;
+    }
+    if (!ok) throw std::invalid_argument("Failed to parse scores: invalid digit found in string");
+    scores.push_back((int32_t)v);
+    if (comma == std::string::npos) break;
+    pos = comma + 1;
+  }
+  AlignmentParams p;
+  p.max_divergence.reset();
+  if (scores.size() == 4 || scores.size() == 6) {
+    p.match_score = scores[0];
+    p.mismatch_penalty = scores[1];
+    p.gap_open = scores[2];
+    p.gap_extend = scores[3];
+    if (scores.size() == 6) { p.gap2_open = scores[4]; p.gap2_extend = scores[5]; }
+    else { p.gap2_open.reset(); p.gap2_extend.reset(); }
+    return p;
+  }
+  throw std::invalid_argument("Invalid number of scores: " + std::to_string(scores.size()) + ". Expected 4 or 6 values.");
+}
+
+static inline void append_uint(std::string& out, size_t v) {
+  char buf[24];
+  int n = 0;
+  do { buf[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (n) out.push_back(buf[--n]);
+}
+
+static void append_cigar(std::string& out, const uint8_t* ops, size_t n) {  // alignment.rs:347-376
+  size_t i = 0;
+  while (i < n) {
+    const uint8_t op = ops[i];
+    size_t j = i + 1;
+    while (j < n && ops[j] == op) ++j;
+    append_uint(out, j - i);
+    out.push_back(op == 'M' ? '=' : op == 'X' ? 'X' : op == 'I' ? 'D' : op == 'D' ? 'I' : '?');
+    i = j;
+  }
+}
+
+std::string cigar_bytes_to_string(const uint8_t* ops, size_t n) {
+  std::string s;
+  append_cigar(s, ops, n);
+  return s;
+}
+
+std::vector<uint8_t> reverse_complement(const std::vector<uint8_t>& seq) {  // alignment.rs:178-190
+  std::vector<uint8_t> out(seq.size());
+  for (size_t i = 0; i < seq.size(); ++i) {
+    uint8_t b = seq[seq.size() - 1 - i], c;
+    switch (b) {
+      case 'A': case 'a': c = 'T'; break;
+      case 'T': case 't': c = 'A'; break;
+      case 'C': case 'c': c = 'G'; break;
+      case 'G': case 'g': c = 'C'; break;
+      default: c = 'N'; break;
+    }
+    out[i] = c;
+  }
+  return out;
+}
+
+void append_paf(std::string& out, const AlignmentResult& r, const uint8_t* ops, size_t nops,
+                const std::vector<Sequence>& sequences) {  // lib.rs:71-112
+  const Sequence& q = sequences[r.query_idx];
+  const Sequence& t = sequences[r.target_idx];
+  const size_t qa = r.query_end - r.query_start, ta = r.target_end - r.target_start;
+  const size_t block_len = std::max(ta, qa);
+  const double identity = r.alignment_length > 0 ? (double)r.num_matches / (double)r.alignment_length : 0.0;
+  out += q.id; out.push_back('\t');
+  append_uint(out, q.seq.size()); out.push_back('\t');
+  append_uint(out, r.query_start); out.push_back('\t');
+  append_uint(out, r.query_end); out.push_back('\t');
+  out.push_back(r.is_reverse ? '-' : '+'); out.push_back('\t');
+  out += t.id; out.push_back('\t');
+  append_uint(out, t.seq.size()); out.push_back('\t');
+  append_uint(out, r.target_start); out.push_back('\t');
+  append_uint(out, r.target_end); out.push_back('\t');
+  append_uint(out, r.num_matches); out.push_back('\t');
+  append_uint(out, block_len); out.push_back('\t');
+  out += "60\tgi:f:";
+  char buf[32];
+  snprintf(buf, sizeof(buf), "%.6f", identity);
+  out += buf;
+  out += "\tcg:Z:";
+  append_cigar(out, ops, nops);
+}
+
+std::string alignment_to_paf(const AlignmentResult& r, const std::vector<Sequence>& sequences) {
+  std::string s;
+  append_paf(s, r, r.cigar_bytes.data(), r.cigar_bytes.size(), sequences);
+  return s;
+}
+
+// ---- iterator.rs ----------------------------------------------------------------------------
+namespace {
+struct EngineHolder {
+  awv_engine* e = nullptr;
+  explicit EngineHolder(int device) {
+    awv_engine_config cfg{};
+    cfg.device = device;
+    if (awv_engine_create(&cfg, &e) != AWV_OK) throw AlignmentError(std::string("engine: ") + awv_last_error());
+  }
+  ~EngineHolder() { awv_engine_destroy(e); }
+};
+
+void upload(awv_engine* e, const std::vector<Sequence>& seqs) {
+  std::vector<uint64_t> offs(seqs.size() + 1, 0);
+  for (size_t i = 0; i < seqs.size(); ++i) offs[i + 1] = offs[i] + seqs[i].seq.size();
+  std::vector<uint8_t> cat(offs.back() + 1);
+  for (size_t i = 0; i < seqs.size(); ++i)
+    if (!seqs[i].seq.empty()) memcpy(cat.data() + offs[i], seqs[i].seq.data(), seqs[i].seq.size());
+  if (awv_engine_set_sequences(e, (int32_t)seqs.size(), cat.data(), offs.data()) != AWV_OK)
+    throw AlignmentError(std::string("set_sequences: ") + awv_last_error());
+}
+
+// align_pair's result mapping (alignment.rs:42-65, 239-253)
+AlignmentResult make_result(size_t qi, size_t ti, bool is_rev, const awv_result& r, const uint8_t* arena, bool copy_cigar) {
+  AlignmentResult a;
+  a.query_idx = qi;
+  a.target_idx = ti;
+  a.is_reverse = is_rev;
+  if (r.status != AWV_ST_COMPLETED) {  // "empty" alignment on failure, still emitted
+    a.score = INT32_MAX;
+    return a;
+  }
+  a.query_end = (size_t)r.q_end;
+  a.target_end = (size_t)r.t_end;
+  a.score = r.score;
+  a.num_matches = (size_t)r.num_matches;
+  a.alignment_length = (size_t)r.num_matches + (size_t)r.num_mismatches;
+  if (copy_cigar && arena) a.cigar_bytes.assign(arena + r.cigar_off, arena + r.cigar_off + r.cigar_len);
+  return a;
+}
+}  // namespace
+
+AllPairIterator::AllPairIterator(const std::vector<Sequence>& sequences, AlignmentParams params)
+    : sequences_(sequences), params_(std::move(params)), orientation_params_(AlignmentParams::edit_distance()) {
+  const size_t n = sequences.size();
+  for (size_t i = 0; i < n; ++i)
+    for (size_t j = 0; j < n; ++j)
+      if (i != j) pairs_.emplace_back(i, j);  // iterator.rs:38-43 row-major, i != j
+}
+
+AllPairIterator AllPairIterator::with_options(const std::vector<Sequence>& sequences, AlignmentParams params,
+                                              bool exclude_self, bool use_mash_orientation, SparsificationStrategy s) {
+  if (s.kind != SparsificationStrategy::None)
+    throw AlignmentError("sparsification strategies other than None are not built yet (SURVEY.md 8f-3)");
+  AllPairIterator it(sequences, std::move(params));
+  it.exclude_self_ = exclude_self;
+  if (!exclude_self) {  // iterator.rs:44-46
+    it.pairs_.clear();
+    for (size_t i = 0; i < sequences.size(); ++i)
+      for (size_t j = 0; j < sequences.size(); ++j) it.pairs_.emplace_back(i, j);
+  }
+  it.orientation_ = use_mash_orientation ? Orientation::Mash : Orientation::Wfa;
+  return it;
+}
+
+AllPairIterator& AllPairIterator::with_orientation_params(AlignmentParams p) { orientation_params_ = std::move(p); return *this; }
+AllPairIterator& AllPairIterator::with_orientation(Orientation o) { orientation_ = o; return *this; }
+AllPairIterator& AllPairIterator::with_device(int device) { device_ = device; return *this; }
+
+void AllPairIterator::run(const std::function<void(int64_t, int64_t, const awv_result*, const uint8_t*,
+                                                   const std::vector<uint8_t>&)>& batch_cb) {
+  if (orientation_ == Orientation::Mash)
+    throw AlignmentError("mash orientation is not built yet (SURVEY.md 8f-2): use Orientation::Wfa or ForwardOnly");
+  EngineHolder eh(device_);
+  upload(eh.e, sequences_);
+  const int64_t n = (int64_t)pairs_.size();
+  std::vector<uint8_t> is_rev((size_t)n, 0);
+  std::vector<awv_pair> ap((size_t)n);
+  if (orientation_ == Orientation::Wfa) {
+    // determine_orientation_wfa (alignment.rs:157-175): align forward and reverse-complement with the
+    // orientation params, compare #X+#I+#D; forward wins ties; a failed alignment counts as usize::MAX
+    std::vector<awv_pair> op((size_t)2 * n);
+    for (int64_t i = 0; i < n; ++i) {
+      op[2 * i] = awv_pair{(int32_t)pairs_[i].first, (int32_t)pairs_[i].second, 0};
+      op[2 * i + 1] = awv_pair{(int32_t)pairs_[i].first, (int32_t)pairs_[i].second, 1};
+    }
+    std::vector<awv_result> orr((size_t)2 * n);
+    const awv_penalties open = to_penalties(orientation_params_);
+    if (awv_align_pairs(eh.e, &open, op.data(), 2 * n, orr.data(), nullptr, nullptr) != AWV_OK)
+      throw AlignmentError(std::string("orientation pass: ") + awv_last_error());
+    for (int64_t i = 0; i < n; ++i) {
+      auto dist = [](const awv_result& r) -> uint64_t {
+        return r.status == AWV_ST_COMPLETED ? (uint64_t)r.num_mismatches + (uint64_t)r.num_ins + (uint64_t)r.num_del : UINT64_MAX;
+      };
+      is_rev[i] = dist(orr[2 * i]) <= dist(orr[2 * i + 1]) ? 0 : 1;
+    }
+  }
+  for (int64_t i = 0; i < n; ++i) ap[i] = awv_pair{(int32_t)pairs_[i].first, (int32_t)pairs_[i].second, is_rev[i]};
+  using BatchCb = std::function<void(int64_t, int64_t, const awv_result*, const uint8_t*, const std::vector<uint8_t>&)>;
+  struct Ctx {
+    const BatchCb* cb;
+    const std::vector<uint8_t>* rev;
+    std::exception_ptr err;
+  } ctx{&batch_cb, &is_rev, nullptr};
+  auto sink = [](void* user, int64_t first, int64_t cnt, const awv_result* res, const uint8_t* arena) -> int {
+    Ctx* c = (Ctx*)user;
+    try {
+      (*c->cb)(first, cnt, res, arena, *c->rev);
+    } catch (...) {
+      c->err = std::current_exception();  // first error wins and aborts (iterator.rs:220-251)
+      return 1;
+    }
+    return 0;
+  };
+  const awv_penalties pen = to_penalties(params_);
+  const int rc = awv_align_pairs(eh.e, &pen, ap.data(), n, nullptr, sink, &ctx);
+  awv_engine_stats(eh.e, &stats_);
+  if (ctx.err) std::rethrow_exception(ctx.err);
+  if (rc != AWV_OK) throw AlignmentError(std::string("align_pairs: ") + awv_last_error());
+}
+
+void AllPairIterator::for_each_with_callback(const Callback& cb) {
+  run([&](int64_t first, int64_t cnt, const awv_result* res, const uint8_t* arena, const std::vector<uint8_t>& rev) {
+    for (int64_t i = 0; i < cnt; ++i) {
+      const auto& pr = pairs_[(size_t)(first + i)];
+      cb(make_result(pr.first, pr.second, rev[(size_t)(first + i)] != 0, res[i], arena, true));
+    }
+  });
+}
+
+void AllPairIterator::for_each_paf_batch(const std::function<void(const std::string&)>& sink, int format_threads) {
+  run([&](int64_t first, int64_t cnt, const awv_result* res, const uint8_t* arena, const std::vector<uint8_t>& rev) {
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(format_threads, cnt / 64 + 1));
+    std::vector<std::string> parts((size_t)T);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) {
+      th.emplace_back([&, t]() {
+        const int64_t lo = cnt * t / T, hi = cnt * (t + 1) / T;
+        std::string& out = parts[(size_t)t];
+        out.reserve((size_t)(hi - lo) * 4096);
+        for (int64_t i = lo; i < hi; ++i) {
+          const auto& pr = pairs_[(size_t)(first + i)];
+          const AlignmentResult a = make_result(pr.first, pr.second, rev[(size_t)(first + i)] != 0, res[i], arena, false);
+          const bool ok = res[i].status == AWV_ST_COMPLETED;
+          append_paf(out, a, ok ? arena + res[i].cigar_off : nullptr, ok ? res[i].cigar_len : 0, sequences_);
+          out.push_back('\n');
+        }
+      });
+    }
+    for (auto& x : th) x.join();
+    for (const auto& p : parts) sink(p);
+  });
+}
+
+// ---- wfa.rs ---------------------------------------------------------------------------------
+namespace wfa {
+
+std::string validate_cigar_alignment(const uint8_t* cigar, size_t n, size_t query_len, size_t reference_len) {
+  size_t q = 0, r = 0;
+  char buf[160];
+  for (size_t i = 0; i < n; ++i) {
+    const uint8_t op = cigar[i];
+    if (op == 'M' || op == '=' || op == 'X') {
+      if (q >= query_len || r >= reference_len) {
+        snprintf(buf, sizeof(buf), "CIGAR extends beyond sequences at M/=/X op: q_pos=%zu, r_pos=%zu, query_len=%zu, ref_len=%zu",
+                 q, r, query_len, reference_len);
+        return buf;
+      }
+      ++q; ++r;
+    } else if (op == 'I') {  // WFA2: I consumes the reference
+      if (r >= reference_len) {
+        snprintf(buf, sizeof(buf), "CIGAR extends beyond reference at I op: r_pos=%zu, ref_len=%zu", r, reference_len);
+        return buf;
+      }
+      ++r;
+    } else if (op == 'D') {  // WFA2: D consumes the query
+      if (q >= query_len) {
+        snprintf(buf, sizeof(buf), "CIGAR extends beyond query at D op: q_pos=%zu, query_len=%zu", q, query_len);
+        return buf;
+      }
+      ++q;
+    } else {
+      snprintf(buf, sizeof(buf), "Invalid CIGAR operation: %c (0x%02x)", (char)op, op);
+      return buf;
+    }
+  }
+  if (q != query_len) { snprintf(buf, sizeof(buf), "CIGAR doesn't cover full query: %zu vs %zu", q, query_len); return buf; }
+  if (r != reference_len) { snprintf(buf, sizeof(buf), "CIGAR doesn't cover full reference: %zu vs %zu", r, reference_len); return buf; }
+  return "";
+}
+
+AlignmentResult align_sequences(const std::vector<uint8_t>& pattern, const std::vector<uint8_t>& text,
+                                const Penalties& p, AlignmentMode mode, int device) {
+  awv_penalties q{};
+  q.match = 0;
+  q.mismatch = p.mismatch;
+  switch (mode) {  // wfa.rs:185-218
+    case AlignmentMode::EditDistance: q.gap_open1 = p.mismatch; q.gap_ext1 = p.mismatch; break;
+    case AlignmentMode::SinglePieceAffine: q.gap_open1 = p.gap_opening1; q.gap_ext1 = p.gap_extension1; break;
+    case AlignmentMode::TwoPieceAffine:
+      q.gap_open1 = p.gap_opening1; q.gap_ext1 = p.gap_extension1;
+      q.gap_open2 = p.gap_opening2; q.gap_ext2 = p.gap_extension2; q.two_piece = 1;
+      break;
+  }
+  EngineHolder eh(device);
+  std::vector<uint8_t> cig(pattern.size() + text.size() + 1);
+  awv_result r{};
+  if (awv_align_one(eh.e, &q, pattern.data(), (int32_t)pattern.size(), text.data(), (int32_t)text.size(), &r,
+                    cig.data(), cig.size()) != AWV_OK)
+    throw AlignmentError(std::string("Alignment failed: ") + awv_last_error());
+  if (r.status != AWV_ST_COMPLETED) throw AlignmentError("Alignment failed with status: " + std::to_string(r.status));
+  const std::string bad = validate_cigar_alignment(cig.data(), r.cigar_len, pattern.size(), text.size());
+  if (!bad.empty()) throw AlignmentError("CIGAR validation failed: " + bad);
+  AlignmentResult out;
+  out.score = r.score;
+  out.cigar = cigar_bytes_to_string(cig.data(), r.cigar_len);
+  out.matches = (size_t)r.num_matches;
+  out.mismatches = (size_t)r.num_mismatches;
+  out.deletions = (size_t)r.num_ins;   // WFA2 'I' means standard 'D' (wfa.rs:94-96)
+  out.insertions = (size_t)r.num_del;  // WFA2 'D' means standard 'I'
+  out.alignment_length = out.matches + out.mismatches;
+  return out;
+}
+
+}  // namespace wfa
+}  // namespace allwave

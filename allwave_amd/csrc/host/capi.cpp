@@ -1,0 +1,146 @@
+// capi.cpp -- extern "C" hooks over the C++ host mirror so the Python tests and bench.py can drive
+// it through ctypes (plain pointers and sizes only).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "allwave.hpp"
+
+using namespace allwave;
+
+namespace {
+void set_err(char* err, size_t cap, const std::string& m) {
+  if (err && cap) snprintf(err, cap, "%s", m.c_str());
+}
+std::vector<Sequence> make_seqs(int n, const char* const* ids, const uint8_t* bytes, const uint64_t* offs) {
+  std::vector<Sequence> s((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    s[i].id = ids[i];
+    s[i].seq.assign(bytes + offs[i], bytes + offs[i + 1]);
+  }
+  return s;
+}
+}  // namespace
+
+extern "C" {
+
+int awh_parse_scores(const char* s, int32_t out[6], int* n, char* err, size_t cap) {
+  try {
+    const AlignmentParams p = parse_scores(s);
+    out[0] = p.match_score; out[1] = p.mismatch_penalty; out[2] = p.gap_open; out[3] = p.gap_extend;
+    *n = 4;
+    if (p.gap2_open && p.gap2_extend) { out[4] = *p.gap2_open; out[5] = *p.gap2_extend; *n = 6; }
+    const awv_penalties q = to_penalties(p);
+    (void)q;
+    return 0;
+  } catch (const std::exception& e) { set_err(err, cap, e.what()); return -1; }
+}
+
+// mode of AlignmentMode::from_params: 0 edit, 1 single-piece, 2 two-piece; pen = penalties handed to the engine
+int awh_mode_from_scores(const char* s, int* mode, int32_t pen[7], char* err, size_t cap) {
+  try {
+    const AlignmentParams p = parse_scores(s);
+    *mode = (int)alignment_mode_from_params(p);
+    const awv_penalties q = to_penalties(p);
+    pen[0] = q.match; pen[1] = q.mismatch; pen[2] = q.gap_open1; pen[3] = q.gap_ext1; pen[4] = q.gap_open2; pen[5] = q.gap_ext2; pen[6] = q.two_piece;
+    return 0;
+  } catch (const std::exception& e) { set_err(err, cap, e.what()); return -1; }
+}
+
+int awh_cigar_to_string(const uint8_t* ops, size_t n, char* out, size_t cap) {
+  const std::string s = cigar_bytes_to_string(ops, n);
+  if (s.size() + 1 > cap) return -1;
+  memcpy(out, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+
+int awh_reverse_complement(const uint8_t* in, size_t n, uint8_t* out) {
+  const std::vector<uint8_t> r = reverse_complement(std::vector<uint8_t>(in, in + n));
+  if (n) memcpy(out, r.data(), n);
+  return 0;
+}
+
+// Formats one record from explicit fields (unit-tests alignment_to_paf without a GPU).
+int awh_format_paf(const char* qid, size_t qlen, const char* tid, size_t tlen, size_t qs, size_t qe, size_t ts, size_t te,
+                   int is_reverse, size_t num_matches, size_t alignment_length, const uint8_t* ops, size_t nops, char* out,
+                   size_t cap) {
+  std::vector<Sequence> seqs(2);
+  seqs[0].id = qid; seqs[0].seq.assign(qlen, 'A');
+  seqs[1].id = tid; seqs[1].seq.assign(tlen, 'A');
+  AlignmentResult r;
+  r.query_idx = 0; r.target_idx = 1; r.query_start = qs; r.query_end = qe; r.target_start = ts; r.target_end = te;
+  r.is_reverse = is_reverse != 0; r.num_matches = num_matches; r.alignment_length = alignment_length;
+  r.cigar_bytes.assign(ops, ops + nops);
+  const std::string s = alignment_to_paf(r, seqs);
+  if (s.size() + 1 > cap) return -1;
+  memcpy(out, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+
+int awh_all_pairs_paf(int n, const char* const* ids, const uint8_t* bytes, const uint64_t* offs, const char* scores,
+                      int orientation, int exclude_self, int device, char** out, size_t* out_len, char* err, size_t cap) {
+  try {
+    const std::vector<Sequence> seqs = make_seqs(n, ids, bytes, offs);
+    AllPairIterator it = AllPairIterator::with_options(seqs, parse_scores(scores), exclude_self != 0, orientation == 2,
+                                                      SparsificationStrategy{});
+    it.with_orientation(orientation == 0 ? Orientation::ForwardOnly : orientation == 1 ? Orientation::Wfa : Orientation::Mash);
+    it.with_device(device);
+    std::string all;
+    it.for_each_with_callback([&](AlignmentResult&& r) {  // the reference's own per-record path
+      all += alignment_to_paf(r, seqs);
+      all.push_back('\n');
+    });
+    *out = (char*)malloc(all.size() + 1);
+    memcpy(*out, all.c_str(), all.size() + 1);
+    *out_len = all.size();
+    return 0;
+  } catch (const std::exception& e) { set_err(err, cap, e.what()); return -1; }
+}
+
+// End-to-end measurement: sequences -> GPU alignment -> D2H -> PAF text into a counting sink.
+int awh_all_pairs_paf_count(int n, const char* const* ids, const uint8_t* bytes, const uint64_t* offs, const char* scores,
+                            int orientation, int device, int format_threads, uint64_t* out_bytes, uint64_t* out_lines,
+                            double* secs, awv_stats* st, char* err, size_t cap) {
+  try {
+    const std::vector<Sequence> seqs = make_seqs(n, ids, bytes, offs);
+    AllPairIterator it(seqs, parse_scores(scores));
+    it.with_orientation(orientation == 0 ? Orientation::ForwardOnly : Orientation::Wfa).with_device(device);
+    uint64_t nb = 0, nl = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    it.for_each_paf_batch([&](const std::string& s) {
+      nb += s.size();
+      for (char c : s) nl += c == '\n';
+    }, format_threads);
+    *secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *out_bytes = nb;
+    *out_lines = nl;
+    if (st) *st = it.last_stats();
+    return 0;
+  } catch (const std::exception& e) { set_err(err, cap, e.what()); return -1; }
+}
+
+int awh_align_sequences(const uint8_t* pattern, size_t plen, const uint8_t* text, size_t tlen, const int32_t pen[5], int mode,
+                        int device, int32_t* score, char* cigar, size_t ccap, uint64_t counts[5], char* err, size_t cap) {
+  try {
+    const wfa::Penalties p{pen[0], pen[1], pen[2], pen[3], pen[4]};
+    const wfa::AlignmentResult r = wfa::align_sequences(std::vector<uint8_t>(pattern, pattern + plen),
+                                                        std::vector<uint8_t>(text, text + tlen), p, (AlignmentMode)mode, device);
+    *score = r.score;
+    if (r.cigar.size() + 1 > ccap) { set_err(err, cap, "cigar buffer too small"); return -2; }
+    memcpy(cigar, r.cigar.c_str(), r.cigar.size() + 1);
+    counts[0] = r.matches; counts[1] = r.mismatches; counts[2] = r.insertions; counts[3] = r.deletions; counts[4] = r.alignment_length;
+    return 0;
+  } catch (const std::exception& e) { set_err(err, cap, e.what()); return -1; }
+}
+
+int awh_validate_cigar(const uint8_t* cigar, size_t n, size_t qlen, size_t rlen, char* err, size_t cap) {
+  const std::string m = wfa::validate_cigar_alignment(cigar, n, qlen, rlen);
+  if (m.empty()) return 0;
+  set_err(err, cap, m);
+  return -1;
+}
+
+void awh_free(void* p) { free(p); }
+
+}  // extern "C"

@@ -22,7 +22,8 @@ EXPORTS = ("awv_abi_version", "awv_last_error", "awv_engine_create", "awv_engine
 
 class EngineConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("workgroups", C.c_int32), ("max_batch_pairs", C.c_int64),
-                ("max_arena_bytes", C.c_int64), ("flags", C.c_int32), ("reserved", C.c_int32)]
+                ("max_arena_bytes", C.c_int64), ("flags", C.c_int32), ("reserved", C.c_int32),
+                ("max_scratch_bytes", C.c_int64)]
 
 
 class Penalties(C.Structure):
@@ -92,10 +93,10 @@ class EngineError(RuntimeError):
 class Engine:
     """One engine per GPU (owns device copies of the sequences, scratch arenas, one stream)."""
 
-    def __init__(self, device=0, workgroups=0, max_batch_pairs=0, max_arena_bytes=0, flags=0):
+    def __init__(self, device=0, workgroups=0, max_batch_pairs=0, max_arena_bytes=0, flags=0, max_scratch_bytes=0):
         L = load()
         self._h = C.c_void_p()
-        cfg = EngineConfig(device, workgroups, max_batch_pairs, max_arena_bytes, flags, 0)
+        cfg = EngineConfig(device, workgroups, max_batch_pairs, max_arena_bytes, flags, 0, max_scratch_bytes)
         rc = L.awv_engine_create(C.byref(cfg), C.byref(self._h))
         if rc != AWV_OK:
             self._h = C.c_void_p()

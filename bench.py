@@ -51,22 +51,18 @@ def main():
     ap.add_argument("--workgroups", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-paf", action="store_true", help="skip the end-to-end PAF formatting figure")
     args = ap.parse_args()
 
     import numpy as np
     import torch  # first: the engine then binds to the HIP runtime torch already loaded
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from allwave_amd import dist as D
+    rank, local_rank, world = D.env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    dist = D.init(backend="nccl") if world > 1 else None  # RCCL: only the barrier + the final reduction
 
     from allwave_amd import ffi, synth
 
@@ -81,9 +77,7 @@ def main():
     eng.set_sequences((data, offs))  # resident in HBM before the timed region
 
     def barrier():
-        if dist is not None:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
+        D.barrier(dist, local_rank)
 
     res = None
     for _ in range(args.warmup):
@@ -107,22 +101,18 @@ def main():
     if (res["status"] != 0).any():
         raise SystemExit("bench: %d pairs did not complete" % int((res["status"] != 0).sum()))
 
-    tot = torch.tensor([elapsed, float(bp), float(done)], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        tmax = tot[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        sums = tot[1:].clone()
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        elapsed_max, bp_all, done_all = float(tmax[0]), float(sums[0]), float(sums[1])
-    else:
-        elapsed_max, bp_all, done_all = elapsed, float(bp), float(done)
+    elapsed_max, (bp_all, done_all) = D.reduce_max_sum(dist, elapsed, [bp, done])
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    bytes_per_cell = 48 if len(scores) == 6 else 28
+    # algorithmic bytes per cell-step: every component row written once and each source row
+    # read once -- 2-piece: 5 written + 7 read = 12 offsets, 1-piece: 3 + 4 = 7 -- at the row element
+    # size the launch used (2 B when all lengths < 32760, else 4 B; SURVEY 8d quotes the 4-byte figure)
+    esz = 2 if cfg["length"] < 32000 else 4
+    bytes_per_cell = (12 if len(scores) == 6 else 7) * esz
     algo_bytes = cells * bytes_per_cell + ext * 16 + cig_bytes
     kern_s = kernel_ms * 1e-3
     achieved = algo_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
@@ -146,7 +136,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "int32",
+        "dtype": "int16" if cfg["length"] < 32000 else "int32",
         "data": "synthetic",
         "config": {"workload": "%s: %d x %d bp synthetic, %.0f%% divergence, -p none, scores %s, %d pairs per GPU per step"
                                % (args.config, cfg["nseq"], cfg["length"], 100 * cfg["d"],
@@ -156,9 +146,23 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel": "biwfa_align_kernel", "avg_launch_ms": kernel_ms / max(launches, 1),
-                     "cell_steps_per_launch": cells / max(launches, 1),
+                     "cell_steps_per_launch": cells / max(launches, 1), "bytes_per_cell_step": bytes_per_cell,
                      "algorithmic_bytes_per_launch": algo_bytes / max(launches, 1)},
     }
+
+    if world == 1 and not args.no_paf:
+        # secondary figure (not `value`): the whole boundary end to end -- sequences on the host ->
+        # upload -> align -> CIGARs over PCIe -> alignment_to_paf text (C++ host mirror) into a sink
+        from allwave_amd import host as H
+        nsub = min(cfg["nseq"], 96)
+        seqs = [bytes(data[offs[i]:offs[i + 1]]) for i in range(nsub)]
+        nb, nl, secs, hst = H.all_pairs_paf_count(["s%05d" % i for i in range(nsub)], seqs,
+                                                  ",".join(map(str, scores)), orientation="forward",
+                                                  device=local_rank, format_threads=usable_cores())
+        out["paf_end_to_end"] = {"lines_per_s": nl / secs, "bp_per_s": sum(len(s) for s in seqs) * (nsub - 1) / secs,
+                                 "pairs": nl, "paf_bytes": nb, "seconds": secs, "d2h_ms": hst.d2h_ms,
+                                 "what": "first %d sequences all-pairs: H2D + kernel + CIGAR D2H over PCIe + PAF "
+                                         "formatting on %d host threads into a memory sink" % (nsub, usable_cores())}
 
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O  # the reported CPU baseline (kind "port"), never the product

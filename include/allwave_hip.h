@@ -66,11 +66,12 @@ typedef struct awv_engine awv_engine;
 
 typedef struct {
   int32_t device;          /* HIP device ordinal */
-  int32_t workgroups;      /* persistent workgroups (0 = engine default: 3 per CU) */
+  int32_t workgroups;      /* persistent workgroups = pairs in flight (0 = engine default: 16 per CU) */
   int64_t max_batch_pairs; /* pairs per launch (0 = default) */
   int64_t max_arena_bytes; /* CIGAR arena budget per launch (0 = default 8 GiB) */
   int32_t flags;           /* AWV_F_* */
   int32_t reserved;
+  int64_t max_scratch_bytes; /* cap on the per-workgroup wavefront arenas (0 = default 160 GiB) */
 } awv_engine_config;
 
 #define AWV_F_KEEP_ON_DEVICE 1 /* do not copy CIGARs back (kernel-only measurements) */

@@ -26,7 +26,7 @@ def test_header_symbols_exported(hip_lib):
 
 def test_struct_layouts_match_header():
     from allwave_amd import ffi
-    assert C.sizeof(ffi.EngineConfig) == 32
+    assert C.sizeof(ffi.EngineConfig) == 40
     assert C.sizeof(ffi.Penalties) == 28
     assert ffi.PAIR_DTYPE.itemsize == 12
     assert ffi.RESULT_DTYPE.itemsize == 48
