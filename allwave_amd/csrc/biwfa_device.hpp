@@ -78,6 +78,9 @@ struct KParams {
   const uint8_t* seq[4];  // 0 fwd, 1 reversed, 2 reverse-complement, 3 reversed reverse-complement
   const uint64_t* seq_off;
   const int32_t* seq_len;
+  const uint32_t* seq2[2];     // 2-bit packed forward / reverse-complement (16 bases per word, base i in bits 2(i%16))
+  const uint64_t* seq2_off;    // word offset of each sequence in seq2[*]
+  const uint8_t* seq2_ok;      // bit0: forward bytes are all upper-case ACGT, bit1: the reverse complement is
   const int32_t* pair_q;
   const int32_t* pair_t;
   const int32_t* pair_rc;
@@ -93,8 +96,12 @@ struct KParams {
   int wb_cap;      // base-case columns per row
   void* hist_mem;
   size_t hist_slot_stride;  // bytes per workgroup slot
+  size_t hist_meta_offset;  // byte offset of the base-case metadata log inside a hist slot
   uint32_t* ev_mem;
   size_t ev_slot_stride;
+  int* chunk_mem;            // per workgroup: [2 dirs][ring][chunks_cap] max antidiagonal of each 256-column chunk of the M row
+  size_t chunk_slot_stride;  // ints per workgroup
+  int chunks_cap;
   uint8_t* cigar;
   const uint64_t* cigar_off;
   DevResult* results;
@@ -112,30 +119,34 @@ struct Breakpoint { int score, sf, sr, kf, kr, off_f, off_r, comp; };
 // LDS: a small static part plus one dynamic region carved per launch (sizes depend on the
 // penalties' ring depth, the base-case score capacity and the sequence staging budget):
 //   [ bi_meta[2][NCOMP][ring] | bi_A[2][ring] | bi_oob[2][ring] | firstk[scope*NCOMP] ]  (BiWFA search)
-//   aliased with base_meta[(sb_cap+1)*NCOMP]                                             (base case)
 //   [ seq: the sub-problem's pattern and text bytes, 8-byte padded ]
-struct RowMeta16 { int16_t lo, hi; };  // base-case rows: |k| <= sb_cap + padding fits 16 bits; empty = {1, 0}
-struct BaseMetaRef {                   // proxy so base_meta[i] reads/writes RowMeta transparently
-  RowMeta16* p;
-  __device__ __forceinline__ operator RowMeta() const {
-    const RowMeta16 m = *p;
-    return m.lo > m.hi ? ROW_EMPTY : RowMeta{m.lo, m.hi};
-  }
-  __device__ __forceinline__ void operator=(const RowMeta& m) const {
-    *p = m.lo > m.hi ? RowMeta16{1, 0} : RowMeta16{(int16_t)m.lo, (int16_t)m.hi};
-  }
-};
-struct BaseMeta {
-  RowMeta16* p;
-  __device__ __forceinline__ BaseMetaRef operator[](int i) const { return BaseMetaRef{p + i}; }
-};
+struct RowMeta16 { int16_t lo, hi; };  // |k| < 32760 whenever 16-bit rows are in use; empty = {1, 0}
+template <typename OffT> struct MetaTraits;
+template <> struct MetaTraits<int16_t> { typedef RowMeta16 Stored; };
+template <> struct MetaTraits<int32_t> { typedef RowMeta Stored; };
+__device__ __forceinline__ RowMeta meta_load(const RowMeta16* p) {
+  const RowMeta16 m = *p;
+  return m.lo > m.hi ? ROW_EMPTY : RowMeta{m.lo, m.hi};
+}
+__device__ __forceinline__ RowMeta meta_load(const RowMeta* p) { return *p; }
+__device__ __forceinline__ void meta_store(RowMeta16* p, const RowMeta& m) {
+  *p = m.lo > m.hi ? RowMeta16{1, 0} : RowMeta16{(int16_t)m.lo, (int16_t)m.hi};
+}
+__device__ __forceinline__ void meta_store(RowMeta* p, const RowMeta& m) { *p = m; }
+
+// LDS: a small static part plus one dynamic region carved per launch:
+//   [ ring_meta[2][NCOMP][ring] | bi_A[2][ring] | bi_oob[2][ring] | firstk[scope*NCOMP] | seq ]
+// The base case (one direction) reuses ring_meta[0]; its full per-score metadata history, which
+// only the backtrace reads, is logged to the workgroup's HBM arena instead of LDS.
+template <typename OffT>
 struct Lds {
-  RowMeta* bi_meta;
+  typename MetaTraits<OffT>::Stored* ring_meta;
   int* bi_A;
   int* bi_oob;
   int* firstk;
-  BaseMeta base_meta;
-  uint8_t* seq;
+  uint32_t* seq;   // sequence staging (2-bit packed words, or raw bytes)
+  RowMeta* meta_log;  // HBM: [score][NCOMP] of the running base case
+  int* chunk_ak;      // HBM: [dir][ring slot][chunk] max antidiagonal per 256-column chunk (overlap filter)
 };
 struct Shared {
   Acc acc[3][2];
@@ -152,6 +163,7 @@ struct Shared {
 // sequence reads go through explicit global-address-space pointers (global_load + SGPR base).
 typedef const __attribute__((address_space(1))) uint8_t* gseq_t;
 typedef uint64_t u64_unaligned __attribute__((aligned(1)));
+typedef const __attribute__((address_space(1))) uint32_t* gwords_t;
 __device__ __forceinline__ gseq_t to_global(const uint8_t* p) { return (gseq_t)(uintptr_t)p; }
 
 struct SubCtx {
@@ -160,8 +172,12 @@ struct SubCtx {
   gseq_t T[2];
   int kmin[2];
   int wcols;
-  int seq_lds;       // 1: this sub-problem's pattern/text bytes are staged in LDS
-  int p_off, t_off;  // byte offsets of pattern / text in Lds::seq (8-byte aligned, 8-byte padded)
+  // 2-bit packed staging in LDS (only when both sequences are pure upper-case ACGT and the words fit)
+  int seq_mode;            // 0: probes read raw bytes from global memory, 1: packed words staged in LDS
+  int p_w0, t_w0;          // first staged word of pattern / text in Lds::seq (2 pad words before, 3 after)
+  int p_bit, t_bit;        // position (0..15) of the sub-problem's first base inside that word
+  gwords_t Pw, Tw;         // the whole sequences' packed words in HBM (nullptr: not packable)
+  int pb_abs, tb_abs;      // sub-problem start inside the sequences
 };
 
 __device__ __forceinline__ bool row_empty(const RowMeta& m) { return m.lo > m.hi; }
@@ -332,64 +348,71 @@ __device__ __forceinline__ int extend_lcp(gseq_t P, gseq_t T, int v, int h, int 
   return min(n, rem);
 }
 
-// ---- sequences staged in LDS: forward bytes only; the reverse aligner reads the same bytes from
-// the far end (its byte order is mirrored, so leading-zero bytes of the XOR count the matches).
-__device__ __forceinline__ uint64_t lds_ld64(const uint8_t* seq, int addr) {
-  const unsigned* w = reinterpret_cast<const unsigned*>(seq + (addr & ~3));
+// ---- sequences staged in LDS as 2-bit codes (A,C,G,T = 0..3; 16 bases per 32-bit word).  One probe
+// compares 32 bases.  Only forward words are staged: the reverse aligner reads the same words from
+// the far end, where the match count is the number of leading (instead of trailing) zero pairs.
+constexpr int PROBE_PACKED = 32, PROBE_BYTES = 8;
+
+__device__ __forceinline__ uint64_t lds_bits64(const uint32_t* base, int pos) {
+  const uint32_t* w = base + (pos >> 4);
   const unsigned d0 = w[0], d1 = w[1], d2 = w[2];
-  const unsigned sh = (unsigned)addr & 3u;
-  const unsigned lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
-  const unsigned hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+  const unsigned sh = ((unsigned)pos & 15u) * 2u;
+  const unsigned lo = __builtin_amdgcn_alignbit(d1, d0, sh);
+  const unsigned hi = __builtin_amdgcn_alignbit(d2, d1, sh);
   return ((uint64_t)hi << 32) | lo;
 }
 
-// XOR of the next 8 pattern/text bytes at (v, h) of direction `dir`, and the matching-byte count
+// XOR of the next 32 pattern/text bases at (v, h) of direction DIR
 template <int DIR>
-__device__ __forceinline__ uint64_t lds_probe(const uint8_t* seq, const SubCtx& cx, int v, int h) {
-  if (DIR == 0) return lds_ld64(seq, cx.p_off + v) ^ lds_ld64(seq, cx.t_off + h);
-  return lds_ld64(seq, cx.p_off + cx.plen - 8 - v) ^ lds_ld64(seq, cx.t_off + cx.tlen - 8 - h);
+__device__ __forceinline__ uint64_t packed_probe(const uint32_t* seq, const SubCtx& cx, int v, int h) {
+  if (DIR == 0) return lds_bits64(seq + cx.p_w0, cx.p_bit + v) ^ lds_bits64(seq + cx.t_w0, cx.t_bit + h);
+  // the 32 bases that END at forward position (len - v): start = bit + len - v - 32, biased by the 2 pad words
+  return lds_bits64(seq + cx.p_w0 - 2, cx.p_bit + cx.plen - v) ^ lds_bits64(seq + cx.t_w0 - 2, cx.t_bit + cx.tlen - h);
 }
 template <int DIR>
-__device__ __forceinline__ int probe_count(uint64_t x) {
-  if (x == 0) return 8;
-  return DIR == 0 ? (int)(__builtin_ctzll(x) >> 3) : (int)(__builtin_clzll(x) >> 3);
+__device__ __forceinline__ int packed_count(uint64_t x) {
+  if (x == 0) return PROBE_PACKED;
+  return DIR == 0 ? (int)(__builtin_ctzll(x) >> 1) : (int)(__builtin_clzll(x) >> 1);
 }
 
 template <int DIR>
-__device__ __forceinline__ int extend_lcp_lds(const uint8_t* seq, const SubCtx& cx, int v, int h, unsigned& iters) {
+__device__ __forceinline__ int extend_lcp_packed(const uint32_t* seq, const SubCtx& cx, int v, int h, unsigned& iters) {
   const int rem = min(cx.plen - v, cx.tlen - h);
   int n = 0;
   while (n < rem) {
-    const uint64_t x = lds_probe<DIR>(seq, cx, v + n, h + n);
+    const int c = packed_count<DIR>(packed_probe<DIR>(seq, cx, v + n, h + n));
     ++iters;
-    const int c = probe_count<DIR>(x);
     n += c;
-    if (c < 8) break;
+    if (c < PROBE_PACKED) break;
   }
   return min(n, rem);
 }
 
-// Copies the sub-problem's bytes into LDS (all threads; ends with a barrier).  Falls back to
-// global-memory reads when they do not fit the staging budget.
-__device__ __forceinline__ void stage_sequences(const KParams& kp, const Lds& lds, SubCtx& cx) {
-  const int pbytes = (cx.plen + 7) & ~7, tbytes = (cx.tlen + 7) & ~7;
-  cx.p_off = 8;
-  cx.t_off = 8 + pbytes + 16;
-  const int total = cx.t_off + tbytes + 16;
-  cx.seq_lds = total <= kp.lds_seq_bytes ? 1 : 0;
-  if (!cx.seq_lds) return;
-  uint64_t* dp = reinterpret_cast<uint64_t*>(lds.seq + cx.p_off);
-  uint64_t* dt = reinterpret_cast<uint64_t*>(lds.seq + cx.t_off);
-  for (int i = threadIdx.x; i < pbytes / 8; i += WG) dp[i] = ld64u(cx.P[0] + 8u * (unsigned)i);
-  for (int i = threadIdx.x; i < tbytes / 8; i += WG) dt[i] = ld64u(cx.T[0] + 8u * (unsigned)i);
+// Copies the sub-problem's packed words into LDS (all threads; ends with a barrier).  Falls back
+// to raw-byte probes from global memory when the pair is not packable or the words do not fit.
+template <typename OffT>
+__device__ __forceinline__ void stage_sequences(const KParams& kp, const Lds<OffT>& lds, SubCtx& cx) {
+  cx.seq_mode = 0;
+  if (cx.Pw == nullptr || cx.Tw == nullptr) return;
+  const int pw_first = cx.pb_abs >> 4, tw_first = cx.tb_abs >> 4;
+  const int npw = ((cx.pb_abs + cx.plen + 15) >> 4) - pw_first;
+  const int ntw = ((cx.tb_abs + cx.tlen + 15) >> 4) - tw_first;
+  cx.p_bit = cx.pb_abs & 15;
+  cx.t_bit = cx.tb_abs & 15;
+  cx.p_w0 = 2;
+  cx.t_w0 = cx.p_w0 + npw + 3 + 2;
+  const int total_words = cx.t_w0 + ntw + 3;
+  if (total_words * 4 > kp.lds_seq_bytes) return;
+  cx.seq_mode = 1;
+  for (int i = threadIdx.x; i < npw; i += WG) lds.seq[cx.p_w0 + i] = cx.Pw[pw_first + i];
+  for (int i = threadIdx.x; i < ntw; i += WG) lds.seq[cx.t_w0 + i] = cx.Tw[tw_first + i];
   __syncthreads();
 }
 
-template <bool BASE>
-__device__ __forceinline__ RowMeta get_meta(const KParams& kp, const Lds& lds, int dir, int comp, int score) {
+template <typename OffT>
+__device__ __forceinline__ RowMeta get_meta(const KParams& kp, const Lds<OffT>& lds, int dir, int comp, int score) {
   if (score < 0) return ROW_EMPTY;
-  if (BASE) return uni((RowMeta)lds.base_meta[score * NCOMP + comp]);
-  return uni(lds.bi_meta[((dir) * NCOMP + (comp)) * kp.ring + (score & (kp.ring - 1))]);
+  return uni(meta_load(&lds.ring_meta[(dir * NCOMP + comp) * kp.ring + (score & (kp.ring - 1))]));
 }
 
 template <bool BASE, typename OffT>
@@ -416,18 +439,18 @@ __device__ __forceinline__ void hull_add(RowMeta& h, const RowMeta& s, int dlo, 
   h.hi = max(h.hi, s.hi + dhi);
 }
 
-template <bool P2, bool BASE>
-__device__ __forceinline__ void plan_step(const KParams& kp, const Lds& lds, int dir, int score, StepPlan& pl) {
+template <bool P2, bool BASE, typename OffT>
+__device__ __forceinline__ void plan_step(const KParams& kp, const Lds<OffT>& lds, int dir, int score, StepPlan& pl) {
   const DevPenalties& pn = kp.pen;
-  pl.src[0] = get_meta<BASE>(kp, lds, dir, C_M, score - pn.x);
-  pl.src[1] = get_meta<BASE>(kp, lds, dir, C_M, score - pn.o1 - pn.e1);
-  pl.src[2] = get_meta<BASE>(kp, lds, dir, C_I1, score - pn.e1);
-  pl.src[3] = get_meta<BASE>(kp, lds, dir, C_D1, score - pn.e1);
+  pl.src[0] = get_meta<OffT>(kp, lds, dir, C_M, score - pn.x);
+  pl.src[1] = get_meta<OffT>(kp, lds, dir, C_M, score - pn.o1 - pn.e1);
+  pl.src[2] = get_meta<OffT>(kp, lds, dir, C_I1, score - pn.e1);
+  pl.src[3] = get_meta<OffT>(kp, lds, dir, C_D1, score - pn.e1);
   pl.src[4] = pl.src[5] = pl.src[6] = ROW_EMPTY;
   if (P2) {
-    pl.src[4] = get_meta<BASE>(kp, lds, dir, C_M, score - pn.o2 - pn.e2);
-    pl.src[5] = get_meta<BASE>(kp, lds, dir, C_I2, score - pn.e2);
-    pl.src[6] = get_meta<BASE>(kp, lds, dir, C_D2, score - pn.e2);
+    pl.src[4] = get_meta<OffT>(kp, lds, dir, C_M, score - pn.o2 - pn.e2);
+    pl.src[5] = get_meta<OffT>(kp, lds, dir, C_I2, score - pn.e2);
+    pl.src[6] = get_meta<OffT>(kp, lds, dir, C_D2, score - pn.e2);
   }
   // Predicted hulls (exact unless some value goes out of bounds, which the step detects and then
   // repairs in trim_pass): a cell of I (D) is non-NULL iff its left (right) source cell is, M iff
@@ -458,8 +481,8 @@ __device__ __forceinline__ void plan_step(const KParams& kp, const Lds& lds, int
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c) {
     if (pred[c].lo > pred[c].hi) pred[c] = ROW_EMPTY;
-    if (BASE) lds.base_meta[score * NCOMP + c] = pred[c];
-    else lds.bi_meta[(dir * NCOMP + c) * kp.ring + (score & (kp.ring - 1))] = pred[c];
+    meta_store(&lds.ring_meta[(dir * NCOMP + c) * kp.ring + (score & (kp.ring - 1))], pred[c]);
+    if (BASE && (threadIdx.x & 63) == 0) lds.meta_log[score * NCOMP + c] = pred[c];  // history for the backtrace
   }
 }
 
@@ -468,11 +491,12 @@ __device__ __forceinline__ void plan_step(const KParams& kp, const Lds& lds, int
 // vector loads.  Output rows are written untrimmed; max antidiagonal / oob land in `acc`.
 // Returns the number of cells.
 template <bool P2, bool BASE, typename OffT>
-__device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const Lds& lds, const SubCtx& cx, rsrc_t rs,
+__device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const Lds<OffT>& lds, const SubCtx& cx, rsrc_t rs,
                                            int dir, int score, const StepPlan& pl, Acc& acc, unsigned& ext_iters) {
   constexpr int VEC = OffTraits<OffT>::VEC;
   static_assert(VEC == 4, "lane vectors are 4 diagonals wide");
   constexpr int WSPAN = 64 * VEC;
+  static_assert(WSPAN == 256, "chunk = 256 columns");
   constexpr int ESZ = (int)sizeof(OffT);
   const DevPenalties& pn = kp.pen;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -599,8 +623,8 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     // probe offset 0, always readable), then the rare long runs continue in a loop
     int rr[VEC], vv[VEC], hh[VEC];
     uint64_t xx[VEC];
-    const bool in_lds = cx.seq_lds != 0;
-    const uint8_t* seq = lds.seq;
+    const bool packed = cx.seq_mode != 0;
+    const uint32_t* seq = lds.seq;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const bool ok = m[j] >= 0;
@@ -609,26 +633,30 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
       rr[j] = ok ? min(plen - vv[j], tlen - hh[j]) : 0;
     }
     // uniform branches hoisted out of the per-cell code so the four probes stay back to back
-    if (in_lds) {
+    int cont = 0;
+    if (packed) {
       if (dir == 0) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) xx[j] = lds_probe<0>(seq, cx, vv[j], hh[j]);
+        for (int j = 0; j < VEC; ++j) xx[j] = packed_probe<0>(seq, cx, vv[j], hh[j]);
       } else {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) xx[j] = lds_probe<1>(seq, cx, vv[j], hh[j]);
+        for (int j = 0; j < VEC; ++j) xx[j] = packed_probe<1>(seq, cx, vv[j], hh[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        int n = dir == 0 ? packed_count<0>(xx[j]) : packed_count<1>(xx[j]);
+        cont |= (n == PROBE_PACKED && rr[j] > PROBE_PACKED) ? (1 << j) : 0;
+        m[j] += min(n, rr[j]);  // rr == 0 for NULL cells: unchanged
       }
     } else {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) xx[j] = ld64u(Pp + (unsigned)vv[j]) ^ ld64u(Tp + (unsigned)hh[j]);
-    }
-    int cont = 0;
-    const bool mirrored = in_lds && dir == 1;  // LDS holds forward bytes: the reverse aligner counts from the top
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      int n = mirrored ? probe_count<1>(xx[j]) : probe_count<0>(xx[j]);
-      cont |= (n == 8 && rr[j] > 8) ? (1 << j) : 0;
-      n = min(n, rr[j]);
-      m[j] += n;  // rr == 0 for NULL cells: unchanged
+      for (int j = 0; j < VEC; ++j) {
+        int n = xx[j] ? (int)(__builtin_ctzll(xx[j]) >> 3) : PROBE_BYTES;
+        cont |= (n == PROBE_BYTES && rr[j] > PROBE_BYTES) ? (1 << j) : 0;
+        m[j] += min(n, rr[j]);
+      }
     }
     ext_iters += VEC;
     if (cont) {
@@ -636,7 +664,7 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
       for (int j = 0; j < VEC; ++j) {
         if (cont & (1 << j)) {
           const int v = m[j] - (k0 + j), h = m[j];
-          if (in_lds) m[j] += dir == 0 ? extend_lcp_lds<0>(seq, cx, v, h, ext_iters) : extend_lcp_lds<1>(seq, cx, v, h, ext_iters);
+          if (packed) m[j] += dir == 0 ? extend_lcp_packed<0>(seq, cx, v, h, ext_iters) : extend_lcp_packed<1>(seq, cx, v, h, ext_iters);
           else m[j] += extend_lcp(Pp, Tp, v, h, plen, tlen, ext_iters);
         }
       }
@@ -644,15 +672,23 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_EXTEND, tc2);
     const unsigned long long tc3 = PROF_NOW();
+    int it_maxak = 0;
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
-      if (m[j] >= 0) lane_maxak = max(lane_maxak, 2 * m[j] - (k0 + j));
+      if (m[j] >= 0) it_maxak = max(it_maxak, 2 * m[j] - (k0 + j));
+    if (!BASE) {  // chunk maximum for the overlap filter: this wave-iteration is exactly one 256-column chunk
+      const int cmax = wave_max_i32(it_maxak);
+      if (lane == 0) lds.chunk_ak[((size_t)dir * kp.ring + (score & (kp.ring - 1))) * kp.chunks_cap + (cb >> 8)] = cmax;
+      lane_maxak = max(lane_maxak, cmax);
+    } else {
+      lane_maxak = max(lane_maxak, it_maxak);
+    }
     buf_store_vec<OffT>(rs, voff + ESZ, tM, m, tlen);
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_STORE, tc3);
   }
   const unsigned long long tc4 = PROF_NOW();
-  const int wmax = wave_max_i32(lane_maxak);
+  const int wmax = BASE ? wave_max_i32(lane_maxak) : lane_maxak;  // (already wave-uniform per chunk otherwise)
   const bool woob = __any(lane_oob);
   if (lane == 0) {
     atomicMax(&acc.maxak, wmax);
@@ -706,8 +742,8 @@ __device__ __forceinline__ void trim_pass(const KParams& kp, const SubCtx& cx, v
 
 // after the barrier: every thread writes the same values (benign same-value stores).  The predicted
 // metadata is already in place; only a trimmed row (rare) is patched.
-template <bool BASE>
-__device__ __forceinline__ void finalize_row(const KParams& kp, const Lds& lds, const SubCtx& cx, int dir, int score,
+template <bool BASE, typename OffT>
+__device__ __forceinline__ void finalize_row(const KParams& kp, const Lds<OffT>& lds, const SubCtx& cx, int dir, int score,
                                              const Acc& acc, bool trimmed) {
   if (trimmed) {
     const int kmin = cx.kmin[dir];
@@ -716,8 +752,8 @@ __device__ __forceinline__ void finalize_row(const KParams& kp, const Lds& lds, 
       RowMeta m = ROW_EMPTY;
       const int l = uni(acc.hull_lo[c]), h = uni(acc.hull_hi[c]);
       if (l != INT_MAX) { m.lo = l + kmin; m.hi = h + kmin; }
-      if (BASE) lds.base_meta[score * NCOMP + c] = m;
-      else lds.bi_meta[(dir * NCOMP + c) * kp.ring + (score & (kp.ring - 1))] = m;
+      meta_store(&lds.ring_meta[(dir * NCOMP + c) * kp.ring + (score & (kp.ring - 1))], m);
+      if (BASE && (threadIdx.x & 63) == 0) lds.meta_log[score * NCOMP + c] = m;
     }
   }
   if (!BASE) {
@@ -749,7 +785,7 @@ __device__ __forceinline__ void emit_run(Emit& em, uint8_t op, int len) {
 // Base case: plain WFA with full history + backtrace (A.5), wavefront_bialign_base
 // ---------------------------------------------------------------------------------------------
 template <typename OffT>
-__device__ __forceinline__ int bt_fetch(const KParams& kp, const BaseMeta& base_meta, const OffT* hist, int kmin,
+__device__ __forceinline__ int bt_fetch(const KParams& kp, const RowMeta* base_meta, const OffT* hist, int kmin,
                                         int max_score, int comp, int score, int k, int add, int type) {
   if (score < 0 || score > max_score) return -1;
   const RowMeta m = base_meta[score * NCOMP + comp];
@@ -762,20 +798,24 @@ __device__ __forceinline__ int bt_fetch(const KParams& kp, const BaseMeta& base_
 enum { BT_I1_OPEN = 1, BT_I1_EXT = 2, BT_I2_OPEN = 3, BT_I2_EXT = 4, BT_D1_OPEN = 5, BT_D1_EXT = 6, BT_D2_OPEN = 7, BT_D2_EXT = 8, BT_M = 9 };
 
 template <bool P2, typename OffT>
-__device__ int base_align(const KParams& kp, Shared& sh, const Lds& lds, SubCtx cx, void* hist_mem, rsrc_t hist_rs, uint32_t* events,
+__device__ int base_align(const KParams& kp, Shared& sh, const Lds<OffT>& lds, SubCtx cx, void* hist_mem, rsrc_t hist_rs, uint32_t* events,
                           int cb, int ce, Emit& em, int& penalty_out, unsigned long long* lstats) {
   const DevPenalties& pn = kp.pen;
   const int tid = threadIdx.x, lane = tid & 63;
   const int plen = cx.plen, tlen = cx.tlen;
   OffT* hist = (OffT*)hist_mem;
-  const BaseMeta base_meta = lds.base_meta;
+  const RowMeta* base_meta = lds.meta_log;  // HBM log, written by plan_step / finalize_row
   const int kspan_lo = min(plen, kp.sb_cap), kspan_hi = min(tlen, kp.sb_cap);
   cx.kmin[0] = -kspan_lo - 4 - COL_PAD;
   cx.wcols = kspan_lo + kspan_hi + 9 + 2 * COL_PAD;
   if (cx.wcols > kp.wb_cap) return ST_CAPACITY;
   const int kmin = cx.kmin[0];
   // score 0
-  for (int c = tid; c < NCOMP; c += WG) base_meta[c] = (c == cb) ? RowMeta{0, 0} : ROW_EMPTY;
+  for (int c = tid; c < NCOMP; c += WG) {
+    const RowMeta m0 = (c == cb) ? RowMeta{0, 0} : ROW_EMPTY;
+    meta_store(&lds.ring_meta[c * kp.ring + 0], m0);
+    lds.meta_log[c] = m0;
+  }
   if (tid == 0) {
     unsigned it = 0;
     int v0 = 0;
@@ -794,7 +834,7 @@ __device__ int base_align(const KParams& kp, Shared& sh, const Lds& lds, SubCtx 
   const unsigned long long tb0 = PROF_NOW();
   for (;;) {
     // termination (wavefront_termination_end2end): end component reaches (plen, tlen)
-    const RowMeta me = uni((RowMeta)base_meta[score * NCOMP + ce]);
+    const RowMeta me = get_meta<OffT>(kp, lds, 0, ce, score);
     if (k_end >= me.lo && k_end <= me.hi) {
       const int32_t v = uni(off_load1<OffT>(hist + ((size_t)score * NCOMP + ce) * (size_t)kp.wb_cap + (k_end - kmin)));
       if (v >= tlen) break;
@@ -803,7 +843,7 @@ __device__ int base_align(const KParams& kp, Shared& sh, const Lds& lds, SubCtx 
     if (score > kp.sb_cap) return ST_CAPACITY;
     Acc& acc = sh.acc[pass % 3][0];
     StepPlan pl;
-    plan_step<P2, true>(kp, lds, 0, score, pl);
+    plan_step<P2, true, OffT>(kp, lds, 0, score, pl);
     cells += compute_row<P2, true, OffT>(kp, sh, lds, cx, hist_rs, 0, score, pl, acc, ext_iters);
     __syncthreads();
     if (uni(sh.error)) return uni(sh.error);
@@ -812,7 +852,7 @@ __device__ int base_align(const KParams& kp, Shared& sh, const Lds& lds, SubCtx 
       trim_pass<P2, true, OffT>(kp, cx, hist_mem, 0, score, pl.lo, pl.hi, acc);
       __syncthreads();
     }
-    finalize_row<true>(kp, lds, cx, 0, score, acc, trim);
+    finalize_row<true, OffT>(kp, lds, cx, 0, score, acc, trim);
     if (tid == 0) acc_reset(sh.acc[(pass + 2) % 3][0]);
     ++pass;
   }
@@ -943,7 +983,7 @@ __device__ int base_align(const KParams& kp, Shared& sh, const Lds& lds, SubCtx 
 constexpr int BP_OK = 0, BP_END_REACHED = 100;
 
 template <bool P2, typename OffT>
-__device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds& lds, const SubCtx& cx, void* ring_mem, int d0, int s0,
+__device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& lds, const SubCtx& cx, void* ring_mem, rsrc_t ring_rs, int d0, int s0,
                                 int s1, bool fwd, Breakpoint& bp, unsigned long long* lstats) {
   constexpr int VEC = OffTraits<OffT>::VEC;
   constexpr int WSPAN = 64 * VEC;
@@ -974,27 +1014,57 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds& lds, c
   for (int i = tid; i < pn.scope * NCOMP; i += WG) lds.firstk[i] = INT_MAX;
   __syncthreads();
   // stage 1: parallel scan of every candidate wavefront pair (superset of what the sequential
-  // search visits: the best score only decreases within a call)
-  auto scan = [&](int c, int i, int si) {
-    const RowMeta r0 = uni(lds.bi_meta[((d0) * NCOMP + (c)) * kp.ring + (slot0)]), r1 = uni(lds.bi_meta[((d1) * NCOMP + (c)) * kp.ring + (si & rmask)]);
+  // search visits: the best score only decreases within a call).  Per score pair a chunk mask is
+  // built first: chunk c of side 0 faces chunk (Cm-255)/256 - c of side 1, and only chunk pairs whose
+  // M-row antidiagonal maxima reach plen + tlen can hold an overlap (same bound as the row filter).
+  constexpr int ESZ = (int)sizeof(OffT);
+  const int mirror_chunk = (Cm - 255) >> 8;
+  const int* ck0 = lds.chunk_ak + ((size_t)d0 * kp.ring + slot0) * kp.chunks_cap;
+  auto chunk_mask = [&](int si) -> uint64_t {
+    if (oob0 || uni(lds.bi_oob[(d1) * kp.ring + (si & rmask)])) return ~0ull;
+    const RowMeta m0 = uni(meta_load(&lds.ring_meta[(d0 * NCOMP + C_M) * kp.ring + slot0]));
+    const RowMeta m1 = uni(meta_load(&lds.ring_meta[(d1 * NCOMP + C_M) * kp.ring + (si & rmask)]));
+    if (row_empty(m0) || row_empty(m1)) return 0ull;
+    const int* ck1 = lds.chunk_ak + ((size_t)d1 * kp.ring + (si & rmask)) * kp.chunks_cap;
+    const int c0lo = (m0.lo - kmin0) >> 8, c0hi = (m0.hi - kmin0) >> 8;
+    const int c1lo = (m1.lo - kmin1) >> 8, c1hi = (m1.hi - kmin1) >> 8;
+    if (c0hi >= 64) return ~0ull;  // very wide rows: no chunk filter
+    const int j = lane, j1 = mirror_chunk - lane;
+    bool ok = false;
+    if (j >= c0lo && j <= c0hi && j1 >= c1lo && j1 <= c1hi) ok = ck0[j] + ck1[j1] >= L;
+    return __ballot(ok);
+  };
+  auto scan = [&](int c, int i, int si, uint64_t cmask) {
+    const RowMeta r0 = uni(meta_load(&lds.ring_meta[(d0 * NCOMP + c) * kp.ring + slot0]));
+    const RowMeta r1 = uni(meta_load(&lds.ring_meta[(d1 * NCOMP + c) * kp.ring + (si & rmask)]));
     if (row_empty(r0) || row_empty(r1)) return;
     const int a = max(r0.lo, D - r1.hi), b = min(r0.hi, D - r1.lo);
     if (a > b) return;
-    if (tid == 0) lstats[STAT_OVERLAP] += 1;
-    const OffT* p0 = row_ptr<false, OffT>(kp, ring_mem, d0, c, s0);
-    const OffT* p1 = row_ptr<false, OffT>(kp, ring_mem, d1, c, si);
     const int ca = a - kmin0, cbn = b - kmin0;
-    for (int cbase = (ca & ~(WSPAN - 1)) + WSPAN * wave; cbase <= cbn; cbase += WSPAN * (WG / 64)) {
+    const int chlo = ca >> 8, chhi = cbn >> 8;
+    uint64_t todo;
+    if (chhi >= 64) todo = ~0ull;  // unfiltered: handled by the plain loop below
+    else todo = cmask & ((chhi >= 63 ? ~0ull : ((1ull << (chhi + 1)) - 1)) & ~((1ull << chlo) - 1));
+    if (todo == 0) return;
+    if (tid == 0) lstats[STAT_OVERLAP] += 1;
+    const int so0 = row_off<false, OffT>(kp, d0, c, s0), so1 = row_off<false, OffT>(kp, d1, c, si);
+    int nth = 0;  // waves take the candidate chunks round-robin, each in ascending order
+    for (int ch = chlo; ch <= chhi; ++ch) {
+      if (chhi < 64 && !((todo >> ch) & 1ull)) continue;
+      if ((nth++ % (WG / 64)) != wave) continue;
+      const int cbase = ch << 8;
       const int c0 = cbase + lane * VEC;
+      const RawVec<OffT> q0 = buf_load_raw<OffT>(ring_rs, c0 * ESZ, so0);
+      const RawVec<OffT> q1 = buf_load_raw<OffT>(ring_rs, (Cm - c0 - (VEC - 1)) * ESZ, so1);  // mirrored: v1[VEC-1-j] pairs with v0[j]
       int32_t v0[VEC], v1[VEC];
-      off_load_vec<OffT, VEC>(p0 + c0, v0);
-      off_load_vec<OffT, VEC>(p1 + (Cm - c0 - (VEC - 1)), v1);  // mirrored: v1[VEC-1-j] pairs with v0[j]
+      unpack_raw<OffT>(q0, v0);
+      unpack_raw<OffT>(q1, v1);
       int first = VEC;
 #pragma unroll
       for (int j = VEC - 1; j >= 0; --j) {
         const int col0 = c0 + j;
         const int k0 = col0 + kmin0, k1 = D - k0;
-        const int32_t h0 = v0[j], h1 = v1[VEC - 1 - j];
+        const int32_t h0 = v0[j] < 0 ? OFF_NULL : v0[j], h1 = v1[VEC - 1 - j] < 0 ? OFF_NULL : v1[VEC - 1 - j];
         bool cond = col0 >= ca && col0 <= cbn && (h0 + h1 >= tlen);
         if (c != C_M) {  // indel2indel skips out-of-bounds forward coordinates
           const int kf = fwd ? k0 : k1, hf = fwd ? h0 : h1;
@@ -1015,9 +1085,13 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds& lds, c
     const int si = s1 - i;
     if (si < 0) break;
     if (!group_pass(si)) continue;
-    if (P2 && s0 + si - pn.o2 < bp.score) { scan(C_D2, i, si); scan(C_I2, i, si); }
-    if (s0 + si - pn.o1 < bp.score) { scan(C_D1, i, si); scan(C_I1, i, si); }
-    if (s0 + si < bp.score) scan(C_M, i, si);
+    const bool w2 = P2 && s0 + si - pn.o2 < bp.score, w1 = s0 + si - pn.o1 < bp.score, w0 = s0 + si < bp.score;
+    if (!(w2 || w1 || w0)) continue;
+    const uint64_t cmask = chunk_mask(si);
+    if (cmask == 0) continue;
+    if (w2) { scan(C_D2, i, si, cmask); scan(C_I2, i, si, cmask); }
+    if (w1) { scan(C_D1, i, si, cmask); scan(C_I1, i, si, cmask); }
+    if (w0) scan(C_M, i, si, cmask);
   }
   __syncthreads();
   // stage 2: replay in WFA2's order (per i: D2, I2, D1, I1, M; first k ascending)
@@ -1046,7 +1120,7 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds& lds, c
 }
 
 template <bool P2, typename OffT>
-__device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds& lds, SubCtx cx, void* ring_mem, rsrc_t ring_rs, int cb, int ce,
+__device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& lds, SubCtx cx, void* ring_mem, rsrc_t ring_rs, int cb, int ce,
                                int score_remaining, Breakpoint& bp, unsigned long long* lstats) {
   const DevPenalties& pn = kp.pen;
   const int tid = threadIdx.x;
@@ -1057,23 +1131,23 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds& lds, Su
     long long bound = (long long)score_remaining + 2LL * pn.scope + 16;
     // the diagonal range is also clipped to what a row can hold; a wavefront that outgrows it is
     // detected in compute_row (ST_CAPACITY) and the pair is re-run by the host with wider rows
-    const long long half = (kp.wcap - 2 * COL_PAD - 9 - 64) / 2;
+    const long long half = (kp.wcap - 2 * COL_PAD - 9 - 256) / 2;
     bound = min(bound, half);
     const int blo = (int)min((long long)plen, bound), bhi = (int)min((long long)tlen, bound);
     const int need = -blo - 4 - COL_PAD;
     cx.kmin[0] = need;
     const int D = tlen - plen;
     const int c0 = D - need - need;
-    const int adj = ((63 - c0) % 64 + 64) % 64;
+    const int adj = ((255 - c0) % 256 + 256) % 256;  // mirror on whole 256-column chunks
     cx.kmin[1] = need - adj;
     cx.wcols = blo + bhi + 9 + adj + 2 * COL_PAD;
-    if (cx.wcols > kp.wcap) return ST_CAPACITY;
+    if (cx.wcols > kp.wcap || (cx.wcols >> 8) + 1 > kp.chunks_cap) return ST_CAPACITY;
   }
   // score-0 wavefronts (wavefront_unialign_init by begin component)
   for (int i = tid; i < 2 * NCOMP; i += WG) {
     const int dir = i / NCOMP, c = i % NCOMP;
     const int begin = dir == 0 ? cb : ce;
-    lds.bi_meta[((dir) * NCOMP + (c)) * kp.ring + (0)] = (c == begin) ? RowMeta{0, 0} : ROW_EMPTY;
+    meta_store(&lds.ring_meta[(dir * NCOMP + c) * kp.ring + 0], (c == begin) ? RowMeta{0, 0} : ROW_EMPTY);
   }
   if (tid == 0 || tid == (WG > 64 ? 64 : 1)) {
     const int dir = tid ? 1 : 0;
@@ -1083,6 +1157,7 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds& lds, Su
     if (begin == C_M) v0 = extend_lcp(dir ? cx.P[1] : cx.P[0], dir ? cx.T[1] : cx.T[0], 0, 0, plen, tlen, it);
     row_ptr<false, OffT>(kp, ring_mem, dir, begin, 0)[0 - (dir ? cx.kmin[1] : cx.kmin[0])] = (OffT)v0;
     sh.ext0[dir] = v0;
+    lds.chunk_ak[((size_t)dir * kp.ring + 0) * kp.chunks_cap + ((0 - (dir ? cx.kmin[1] : cx.kmin[0])) >> 8)] = (begin == C_M) ? 2 * v0 : 0;
     lds.bi_A[(dir) * kp.ring + (0)] = (begin == C_M) ? 2 * v0 : 0;
     lds.bi_oob[(dir) * kp.ring + (0)] = 0;
     acc_reset(sh.acc[0][dir]);
@@ -1119,7 +1194,7 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds& lds, Su
         need[dir] = comp[dir] == sc[dir];
         if (need[dir]) {
           StepPlan pl;
-          plan_step<P2, false>(kp, lds, dir, sc[dir] + 1, pl);
+          plan_step<P2, false, OffT>(kp, lds, dir, sc[dir] + 1, pl);
           cells += compute_row<P2, false, OffT>(kp, sh, lds, cx, ring_rs, dir, sc[dir] + 1, pl, a[dir], ext_iters);
           plo[dir] = pl.lo;
           phi[dir] = pl.hi;
@@ -1139,8 +1214,8 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds& lds, Su
           if (trim1) trim_pass<P2, false, OffT>(kp, cx, ring_mem, 1, sc[1] + 1, plo[1], phi[1], a[1]);
           __syncthreads();
         }
-        if (need[0]) { finalize_row<false>(kp, lds, cx, 0, sc[0] + 1, a[0], trim0); comp[0] = sc[0] + 1; }
-        if (need[1]) { finalize_row<false>(kp, lds, cx, 1, sc[1] + 1, a[1], trim1); comp[1] = sc[1] + 1; }
+        if (need[0]) { finalize_row<false, OffT>(kp, lds, cx, 0, sc[0] + 1, a[0], trim0); comp[0] = sc[0] + 1; }
+        if (need[1]) { finalize_row<false, OffT>(kp, lds, cx, 1, sc[1] + 1, a[1], trim1); comp[1] = sc[1] + 1; }
         if (tid == 0) { acc_reset(sh.acc[(pass + 2) % 3][0]); acc_reset(sh.acc[(pass + 2) % 3][1]); }
         ++pass;
         PROF_ADD(STAT_T_BI_FINALIZE, tp2);
@@ -1161,14 +1236,14 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds& lds, Su
         const int min_sr = (sc[1] > pn.scope - 1) ? sc[1] - (pn.scope - 1) : 0;
         if (sc[0] + min_sr - gap_opening >= bp.score) break;
         const unsigned long long to0 = PROF_NOW();
-        bialign_overlap<P2, OffT>(kp, sh, lds, cx, ring_mem, 0, sc[0], sc[1], true, bp, lstats);
+        bialign_overlap<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, 0, sc[0], sc[1], true, bp, lstats);
         PROF_ADD(STAT_T_OVERLAP, to0);
         ++sc[1];
       }
       const int min_sf = (sc[0] > pn.scope - 1) ? sc[0] - (pn.scope - 1) : 0;
       if (min_sf + sc[1] - gap_opening >= bp.score) break;
       const unsigned long long to1 = PROF_NOW();
-      bialign_overlap<P2, OffT>(kp, sh, lds, cx, ring_mem, 1, sc[1], sc[0], false, bp, lstats);
+      bialign_overlap<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, 1, sc[1], sc[0], false, bp, lstats);
       PROF_ADD(STAT_T_OVERLAP, to1);
       ++sc[0];
       last_fwd = true;
@@ -1193,13 +1268,13 @@ __global__ __launch_bounds__(WG, 4) void biwfa_align_kernel(KParams kp) {
   __shared__ Shared sh;
   __shared__ unsigned long long lstats[STAT_N];
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-  Lds lds;
-  lds.bi_meta = reinterpret_cast<RowMeta*>(dyn_smem);
-  lds.bi_A = reinterpret_cast<int*>(lds.bi_meta + 2 * NCOMP * kp.ring);
+  Lds<OffT> lds;
+  typedef typename MetaTraits<OffT>::Stored MetaStored;
+  lds.ring_meta = reinterpret_cast<MetaStored*>(dyn_smem);
+  lds.bi_A = reinterpret_cast<int*>(lds.ring_meta + 2 * NCOMP * kp.ring);
   lds.bi_oob = lds.bi_A + 2 * kp.ring;
   lds.firstk = lds.bi_oob + 2 * kp.ring;
-  lds.base_meta = BaseMeta{reinterpret_cast<RowMeta16*>(dyn_smem)};
-  lds.seq = dyn_smem + kp.lds_meta_bytes;
+  lds.seq = reinterpret_cast<uint32_t*>(dyn_smem + kp.lds_meta_bytes);
   const int tid = threadIdx.x;
   const DevPenalties& pn = kp.pen;
   void* ring_mem = (char*)kp.ring_mem + (size_t)blockIdx.x * kp.ring_slot_stride;
@@ -1207,6 +1282,8 @@ __global__ __launch_bounds__(WG, 4) void biwfa_align_kernel(KParams kp) {
   uint32_t* events = kp.ev_mem + (size_t)blockIdx.x * kp.ev_slot_stride;
   const rsrc_t ring_rs = make_rsrc(ring_mem, kp.ring_slot_stride);
   const rsrc_t hist_rs = make_rsrc(hist, kp.hist_slot_stride);
+  lds.meta_log = reinterpret_cast<RowMeta*>((char*)hist + kp.hist_meta_offset);
+  lds.chunk_ak = kp.chunk_mem + (size_t)blockIdx.x * kp.chunk_slot_stride;
   if (tid < STAT_N) lstats[tid] = 0;
   if (tid < 5) sh.prof[tid] = 0;
   __syncthreads();
@@ -1226,6 +1303,13 @@ __global__ __launch_bounds__(WG, 4) void biwfa_align_kernel(KParams kp) {
     const uint8_t* Pr = kp.seq[qv + 1] + qoff;
     const uint8_t* Tf = kp.seq[0] + toff;
     const uint8_t* Tr = kp.seq[1] + toff;
+    // 2-bit packed views: usable when both sequences are pure upper-case ACGT (bytes compare verbatim)
+    const int qok = (kp.seq2_ok[qi] >> (qv ? 1 : 0)) & 1, tok = kp.seq2_ok[ti] & 1;
+    gwords_t Pw = nullptr, Tw = nullptr;
+    if (qok && tok && kp.lds_seq_bytes > 0) {
+      Pw = (gwords_t)(uintptr_t)(kp.seq2[qv ? 1 : 0] + kp.seq2_off[qi]);
+      Tw = (gwords_t)(uintptr_t)(kp.seq2[0] + kp.seq2_off[ti]);
+    }
     const unsigned long long tt0 = PROF_NOW();
     Emit em;
     em.cig = kp.cigar + kp.cigar_off[pair];
@@ -1268,7 +1352,11 @@ __global__ __launch_bounds__(WG, 4) void biwfa_align_kernel(KParams kp) {
       cx.T[1] = to_global(Tr + (tlenT - t.te));
       cx.kmin[0] = cx.kmin[1] = 0;
       cx.wcols = 0;
-      stage_sequences(kp, lds, cx);
+      cx.Pw = Pw;
+      cx.Tw = Tw;
+      cx.pb_abs = t.pb;
+      cx.tb_abs = t.tb;
+      stage_sequences<OffT>(kp, lds, cx);
       bool do_base = t.score_remaining <= FALLBACK_MIN_SCORE;
       Breakpoint bp;
       if (!do_base) {

@@ -68,9 +68,15 @@ struct SeqSet {
   DevBuf<uint8_t> d_seq[4];
   DevBuf<uint64_t> d_off;
   DevBuf<int32_t> d_len;
+  DevBuf<uint32_t> d_seq2[2];  // 2-bit packed forward / reverse-complement
+  DevBuf<uint64_t> d_off2;     // word offsets
+  DevBuf<uint8_t> d_ok2;       // bit0 forward packable, bit1 reverse-complement packable
   size_t total = 0;
   void release() {
     for (auto& b : d_seq) b.release();
+    for (auto& b : d_seq2) b.release();
+    d_off2.release();
+    d_ok2.release();
     d_off.release();
     d_len.release();
     n = 0;
@@ -100,6 +106,7 @@ struct awv_engine {
   // scratch arenas (per persistent workgroup)
   DevBuf<uint8_t> ring_mem, hist_mem;
   DevBuf<uint32_t> ev_mem;
+  DevBuf<int> chunk_mem;
   // per-launch buffers
   DevBuf<int32_t> d_pair_q, d_pair_t, d_pair_rc;
   DevBuf<uint64_t> d_cigar_off;
@@ -146,7 +153,36 @@ int upload_seqset(awv_engine* e, SeqSet& s, int32_t n, const uint8_t* bytes, con
       cr[j] = cb;         // its reversal
     }
   }
+  // 2-bit packed copies (A,C,G,T -> 0..3, 16 bases per word) for sequences made of upper-case ACGT only;
+  // bytes are compared verbatim by the reference, so anything else keeps the raw-byte path
+  std::vector<uint64_t> off2((size_t)n + 1, 0);
+  std::vector<uint8_t> ok2((size_t)std::max(n, 1), 0);
+  for (int i = 0; i < n; ++i) off2[i + 1] = off2[i] + ((size_t)s.len[i] + 15) / 16 + 1;
+  std::vector<uint32_t> h2[2];
+  for (auto& v : h2) v.assign(off2[n] + 4, 0u);
+  auto code = [](uint8_t b) -> int { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : -1; };
+  for (int i = 0; i < n; ++i) {
+    for (int v = 0; v < 2; ++v) {
+      const uint8_t* src = h[v ? 2 : 0].data() + s.off[i];
+      uint32_t* dst = h2[v].data() + off2[i];
+      bool ok = true;
+      for (size_t j = 0; j < (size_t)s.len[i]; ++j) {
+        const int c = code(src[j]);
+        if (c < 0) { ok = false; break; }
+        dst[j >> 4] |= (uint32_t)c << (2 * (j & 15));
+      }
+      if (ok) ok2[i] |= (uint8_t)(1 << v);
+    }
+  }
   HIP_TRY(hipSetDevice(e->device));
+  for (int v = 0; v < 2; ++v) {
+    if (int rc = s.d_seq2[v].reserve(h2[v].size())) return rc;
+    HIP_TRY(hipMemcpyAsync(s.d_seq2[v].p, h2[v].data(), h2[v].size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+  }
+  if (int rc = s.d_off2.reserve((size_t)n + 1)) return rc;
+  if (int rc = s.d_ok2.reserve(ok2.size())) return rc;
+  HIP_TRY(hipMemcpyAsync(s.d_off2.p, off2.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(s.d_ok2.p, ok2.data(), ok2.size(), hipMemcpyHostToDevice, e->stream));
   for (int v = 0; v < 4; ++v) {
     if (int rc = s.d_seq[v].reserve(s.total)) return rc;
     HIP_TRY(hipMemcpyAsync(s.d_seq[v].p, h[v].data(), s.total, hipMemcpyHostToDevice, e->stream));
@@ -214,10 +250,10 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   const int sb_cap = (int)sb;
   const int wb_cap = ((2 * sb_cap + 9 + 2 * COL_PAD) + 63) & ~63;
   // dynamic LDS: metadata region (BiWFA ring metadata, aliased with the base-case table) + sequences
-  const size_t bi_bytes = (size_t)2 * NCOMP * ring * sizeof(RowMeta) + (size_t)4 * ring * sizeof(int) +
-                          (size_t)dp.scope * NCOMP * sizeof(int);
-  const size_t base_bytes = (size_t)(sb_cap + 1) * NCOMP * sizeof(RowMeta16);
-  const size_t lds_meta = (std::max(bi_bytes, base_bytes) + 15) & ~(size_t)15;
+  auto lds_meta_bytes = [&](size_t meta_elem) {
+    return ((size_t)2 * NCOMP * ring * meta_elem + (size_t)4 * ring * sizeof(int) + (size_t)dp.scope * NCOMP * sizeof(int) + 15) &
+           ~(size_t)15;
+  };
 
   std::vector<int32_t> hq, ht, hrc;
   std::vector<uint64_t> hoff;
@@ -246,31 +282,38 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       maxlen = std::max(maxlen, std::max(ql, tl));
       ++n;
     }
-    int wcap = ((maxsum + 9 + 64 + 2 * COL_PAD) + 63) & ~63;
+    int wcap = ((maxsum + 9 + 256 + 2 * COL_PAD) + 255) & ~255;
     if (const char* env = getenv("AWV_WCAP_MAX")) wcap = std::min(wcap, std::max(2048, atoi(env)));  // experiment knob
     int nslots = (int)std::min<int64_t>(nslots_cfg, n);
     // 16-bit wavefront rows whenever every offset fits (halves the HBM/L2 traffic of the rings)
     // sequence staging: what the largest pair needs, within a 40 KB-per-workgroup LDS budget
     // (4 workgroups per CU of 160 KB); sub-problems that do not fit read global memory instead
-    const size_t seq_need = (size_t)8 + (((size_t)maxlen + 7) & ~(size_t)7) * 2 + 16 + 16 + 16;
-    const size_t lds_budget = (size_t)(160 * 1024 / (1024 / WG)) - 2560;  // 16 waves per CU
-    size_t lds_seq = lds_meta < lds_budget ? std::min(seq_need, lds_budget - lds_meta) : 0;
-    lds_seq &= ~(size_t)15;
-    const size_t dyn_lds = lds_meta + lds_seq;
     const bool narrow = maxlen < 32760 && !(e->cfg.flags & AWV_F_FORCE_INT32);
     const size_t esz = narrow ? 2 : 4;
+    // dynamic LDS = ring metadata (16-bit entries with 16-bit rows) + staging of the 2-bit packed
+    // sequences: what the largest pair needs, within 160 KB / (16 waves per CU) per workgroup
+    const size_t lds_meta = lds_meta_bytes(narrow ? sizeof(RowMeta16) : sizeof(RowMeta));
+    const size_t seq_need = ((((size_t)maxlen + 15) / 16 + 2) * 2 + 10) * 4;
+    const size_t lds_budget = (size_t)(160 * 1024 / (1024 / WG)) - 2048;
+    size_t lds_seq = (e->cfg.flags & AWV_F_NO_PACKED_SEQ) ? 0 : (lds_meta < lds_budget ? std::min(seq_need, lds_budget - lds_meta) : 0);
+    lds_seq &= ~(size_t)15;
+    const size_t dyn_lds = lds_meta + lds_seq;
     const size_t ring_stride = (size_t)2 * NCOMP * ring * wcap * esz;
-    const size_t hist_stride = (size_t)(sb_cap + 1) * NCOMP * wb_cap * esz;
+    const size_t hist_rows = ((size_t)(sb_cap + 1) * NCOMP * wb_cap * esz + 63) & ~(size_t)63;
+    const size_t hist_stride = hist_rows + (((size_t)(sb_cap + 1) * NCOMP * sizeof(RowMeta) + 63) & ~(size_t)63);
     const size_t ev_stride = (size_t)wcap;
+    const int chunks_cap = wcap / 256 + 2;
+    const size_t chunk_stride = (size_t)2 * ring * chunks_cap;
     {  // keep the per-workgroup arenas inside the scratch budget (default 160 GiB of the 288 GB HBM)
       const size_t budget = e->cfg.max_scratch_bytes > 0 ? (size_t)e->cfg.max_scratch_bytes : (size_t)160 << 30;
-      const size_t per_slot = ring_stride + hist_stride + ev_stride * sizeof(uint32_t);
+      const size_t per_slot = ring_stride + hist_stride + ev_stride * sizeof(uint32_t) + chunk_stride * sizeof(int);
       const size_t fit = std::max<size_t>(1, budget / per_slot);
       if ((size_t)nslots > fit) nslots = (int)fit;
     }
     if (int rc = e->ring_mem.reserve(ring_stride * nslots)) return rc;
     if (int rc = e->hist_mem.reserve(hist_stride * nslots)) return rc;
     if (int rc = e->ev_mem.reserve(ev_stride * nslots)) return rc;
+    if (int rc = e->chunk_mem.reserve(chunk_stride * nslots)) return rc;
     if (int rc = e->d_pair_q.reserve((size_t)n)) return rc;
     if (int rc = e->d_pair_t.reserve((size_t)n)) return rc;
     if (int rc = e->d_pair_rc.reserve((size_t)n)) return rc;
@@ -295,6 +338,10 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     for (int v = 0; v < 4; ++v) kp.seq[v] = s.d_seq[v].p;
     kp.seq_off = s.d_off.p;
     kp.seq_len = s.d_len.p;
+    kp.seq2[0] = s.d_seq2[0].p;
+    kp.seq2[1] = s.d_seq2[1].p;
+    kp.seq2_off = s.d_off2.p;
+    kp.seq2_ok = s.d_ok2.p;
     kp.pair_q = e->d_pair_q.p;
     kp.pair_t = e->d_pair_t.p;
     kp.pair_rc = e->d_pair_rc.p;
@@ -310,8 +357,12 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     kp.wb_cap = wb_cap;
     kp.hist_mem = e->hist_mem.p;
     kp.hist_slot_stride = hist_stride;
+    kp.hist_meta_offset = hist_rows;
     kp.ev_mem = e->ev_mem.p;
     kp.ev_slot_stride = ev_stride;
+    kp.chunk_mem = e->chunk_mem.p;
+    kp.chunk_slot_stride = chunk_stride;
+    kp.chunks_cap = chunks_cap;
     kp.cigar = e->d_cigar.p;
     kp.cigar_off = e->d_cigar_off.p;
     kp.results = e->d_results.p;
@@ -368,7 +419,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   e->stats.overlap_scans = stat_tot[STAT_OVERLAP];
   e->stats.aligned_bp = stat_tot[STAT_ALIGNED_BP];
   e->stats.pairs_completed = stat_tot[STAT_PAIRS];
-  e->stats.scratch_bytes = e->ring_mem.bytes() + e->hist_mem.bytes() + e->ev_mem.bytes();
+  e->stats.scratch_bytes = e->ring_mem.bytes() + e->hist_mem.bytes() + e->ev_mem.bytes() + e->chunk_mem.bytes();
   for (int i = 0; i < 14; ++i) e->stats.prof[i] = stat_tot[STAT_T_TOTAL + i];
   return AWV_OK;
 }
@@ -420,6 +471,7 @@ void awv_engine_destroy(awv_engine* e) {
   e->ring_mem.release();
   e->hist_mem.release();
   e->ev_mem.release();
+  e->chunk_mem.release();
   e->d_pair_q.release();
   e->d_pair_t.release();
   e->d_pair_rc.release();
