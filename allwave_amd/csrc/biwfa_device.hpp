@@ -540,17 +540,22 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     // All row loads are issued back to back with no control flow in between (absent rows read a
     // valid dummy row), so the wave waits for memory once; unpack / mask afterwards.
     const unsigned long long tc0 = PROF_NOW();
-    RawVec<OffT> rMx, rO1l, rO1r, rI1, rD1, rO2l, rO2r, rI2, rD2;
-    rMx = buf_load_raw<OffT>(rs, voff + ESZ, sMx);
-    rO1l = buf_load_raw<OffT>(rs, voff, sO1);
-    rO1r = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sO1);
-    rI1 = buf_load_raw<OffT>(rs, voff, sI1);
-    rD1 = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sD1);
-    if (P2) {
-      rO2l = buf_load_raw<OffT>(rs, voff, sO2);
-      rO2r = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sO2);
-      rI2 = buf_load_raw<OffT>(rs, voff, sI2);
-      rD2 = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sD2);
+    // lanes whose four diagonals lie wholly outside [lo, hi] neither load nor store (their values
+    // are NULL by construction and nobody reads outside a row's range): edge chunks cost no traffic
+    const bool lane_on = c0 + VEC > colLo && c0 <= colHi;
+    RawVec<OffT> rMx{}, rO1l{}, rO1r{}, rI1{}, rD1{}, rO2l{}, rO2r{}, rI2{}, rD2{};
+    if (lane_on) {
+      rMx = buf_load_raw<OffT>(rs, voff + ESZ, sMx);
+      rO1l = buf_load_raw<OffT>(rs, voff, sO1);
+      rO1r = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sO1);
+      rI1 = buf_load_raw<OffT>(rs, voff, sI1);
+      rD1 = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sD1);
+      if (P2) {
+        rO2l = buf_load_raw<OffT>(rs, voff, sO2);
+        rO2r = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sO2);
+        rI2 = buf_load_raw<OffT>(rs, voff, sI2);
+        rD2 = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sD2);
+      }
     }
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_LOAD, tc0);
@@ -610,11 +615,13 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
       lane_oob |= mm > hmax;
       m[j] = (mm > hmax || mm < 0) ? OFF_NULL : mm;
     }
-    buf_store_vec<OffT>(rs, voff + ESZ, tI1, ins1, tlen);
-    buf_store_vec<OffT>(rs, voff + ESZ, tD1, del1, tlen);
-    if (P2) {
-      buf_store_vec<OffT>(rs, voff + ESZ, tI2, ins2, tlen);
-      buf_store_vec<OffT>(rs, voff + ESZ, tD2, del2, tlen);
+    if (lane_on) {
+      buf_store_vec<OffT>(rs, voff + ESZ, tI1, ins1, tlen);
+      buf_store_vec<OffT>(rs, voff + ESZ, tD1, del1, tlen);
+      if (P2) {
+        buf_store_vec<OffT>(rs, voff + ESZ, tI2, ins2, tlen);
+        buf_store_vec<OffT>(rs, voff + ESZ, tD2, del2, tlen);
+      }
     }
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_ALU, tc1);
@@ -683,7 +690,7 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     } else {
       lane_maxak = max(lane_maxak, it_maxak);
     }
-    buf_store_vec<OffT>(rs, voff + ESZ, tM, m, tlen);
+    if (lane_on) buf_store_vec<OffT>(rs, voff + ESZ, tM, m, tlen);
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_STORE, tc3);
   }

@@ -14,6 +14,8 @@ LIB_PATH = os.environ.get("AWV_HIP_LIB") or os.path.join(_HERE, "liballwave_hip.
 AWV_OK = 0
 AWV_ERR_NO_DEVICE = -1
 AWV_F_KEEP_ON_DEVICE = 1
+AWV_F_FORCE_INT32 = 2
+AWV_F_NO_PACKED_SEQ = 4
 
 #: every symbol include/allwave_hip.h declares
 EXPORTS = ("awv_abi_version", "awv_last_error", "awv_engine_create", "awv_engine_destroy",

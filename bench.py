@@ -113,7 +113,7 @@ def main():
     # size the launch used (2 B when all lengths < 32760, else 4 B; SURVEY 8d quotes the 4-byte figure)
     esz = 2 if cfg["length"] < 32000 else 4
     bytes_per_cell = (12 if len(scores) == 6 else 7) * esz
-    algo_bytes = cells * bytes_per_cell + ext * 16 + cig_bytes
+    algo_bytes = cells * bytes_per_cell + cig_bytes  # (extend probes read the LDS-staged packed sequences)
     kern_s = kernel_ms * 1e-3
     achieved = algo_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
     traffic = None
@@ -168,14 +168,16 @@ def main():
         from oracle import oracle as O  # the reported CPU baseline (kind "port"), never the product
         cores = usable_cores()
         probe = pairs[:min(len(pairs), 4 * cores)]
-        secs, _, _, _ = O.all_pairs(data, offs, probe, scores, nthreads=cores)
+        # baseline mode of the port: exact overlap pre-filter on (2.4x faster than the plain WFA2-order
+        # search, identical results -- tests/test_oracle.py); the parity check below uses its output
+        secs, _, _, _ = O.all_pairs(data, offs, probe, scores, nthreads=cores, fast_overlap=True)
         rate = len(probe) / max(secs, 1e-6)
         nsample = int(min(len(pairs), max(len(probe), rate * args.cpu_seconds)))
         sample = pairs[:nsample]
-        secs, ores, ost, _ = O.all_pairs(data, offs, sample, scores, nthreads=cores)
+        secs, ores, ost, _ = O.all_pairs(data, offs, sample, scores, nthreads=cores, fast_overlap=True)
         sbp = int(sum(int(offs[a + 1] - offs[a]) for a, _ in sample))
         out["cpu_baseline"] = {"value": sbp / secs, "unit": "bp/s", "cores": cores, "kind": "port",
-                               "sample": "first %d pairs of the same workload, %.1f s, %d threads (one aligner per thread)"
+                               "sample": "first %d pairs of the same workload, %.1f s, %d threads (one aligner per thread, exact overlap pre-filter on)"
                                          % (nsample, secs, cores),
                                "cell_steps": int(ost.cell_steps)}
         g = res[:nsample]

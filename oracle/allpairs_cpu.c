@@ -29,6 +29,7 @@ typedef struct {
   awo_pair_result_t* results;
   atomic_llong* cursor;
   int want_paf;
+  int fast_overlap;
   /* per-thread outputs */
   awo_stats_t stats;
   uint64_t paf_bytes;
@@ -66,6 +67,7 @@ static void* worker_main(void* arg) {
   worker_t* w = (worker_t*)arg;
   awo_aligner_t* A = awo_aligner_new(w->pen);
   if (!A) { w->failed = 1; return NULL; }
+  awo_aligner_set_fast_overlap(A, w->fast_overlap);
   size_t ccap = 1 << 16, pcap = 1 << 17;
   uint8_t* cigar = (uint8_t*)malloc(ccap);
   char* paf = w->want_paf ? (char*)malloc(pcap) : NULL;
@@ -113,9 +115,9 @@ static void* worker_main(void* arg) {
   return NULL;
 }
 
-double awo_all_pairs(const uint8_t* seqs, const uint64_t* offsets, int nseq, const int32_t* pairs, int64_t npairs,
-                     const awo_penalties_t* pen, int nthreads, awo_pair_result_t* results, awo_stats_t* stats_total,
-                     uint64_t* paf_sink_bytes) {
+static double all_pairs_impl(const uint8_t* seqs, const uint64_t* offsets, int nseq, const int32_t* pairs, int64_t npairs,
+                             const awo_penalties_t* pen, int nthreads, awo_pair_result_t* results, awo_stats_t* stats_total,
+                             uint64_t* paf_sink_bytes, int fast_overlap) {
   if (nthreads < 1) nthreads = 1;
   atomic_llong cursor;
   atomic_init(&cursor, 0);
@@ -126,6 +128,7 @@ double awo_all_pairs(const uint8_t* seqs, const uint64_t* offsets, int nseq, con
     ws[i].seqs = seqs; ws[i].offsets = offsets; ws[i].nseq = nseq;
     ws[i].pairs = pairs; ws[i].npairs = npairs; ws[i].pen = pen;
     ws[i].results = results; ws[i].cursor = &cursor; ws[i].want_paf = paf_sink_bytes != NULL;
+    ws[i].fast_overlap = fast_overlap;
     pthread_create(&th[i], NULL, worker_main, &ws[i]);
   }
   for (int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
@@ -151,4 +154,16 @@ double awo_all_pairs(const uint8_t* seqs, const uint64_t* offsets, int nseq, con
   free(ws);
   free(th);
   return failed ? -1.0 : t1 - t0;
+}
+
+double awo_all_pairs(const uint8_t* seqs, const uint64_t* offsets, int nseq, const int32_t* pairs, int64_t npairs,
+                     const awo_penalties_t* pen, int nthreads, awo_pair_result_t* results, awo_stats_t* stats_total,
+                     uint64_t* paf_sink_bytes) {
+  return all_pairs_impl(seqs, offsets, nseq, pairs, npairs, pen, nthreads, results, stats_total, paf_sink_bytes, 0);
+}
+
+double awo_all_pairs_fast(const uint8_t* seqs, const uint64_t* offsets, int nseq, const int32_t* pairs, int64_t npairs,
+                          const awo_penalties_t* pen, int nthreads, awo_pair_result_t* results, awo_stats_t* stats_total,
+                          uint64_t* paf_sink_bytes) {
+  return all_pairs_impl(seqs, offsets, nseq, pairs, npairs, pen, nthreads, results, stats_total, paf_sink_bytes, 1);
 }

@@ -59,6 +59,8 @@ typedef struct {
   bool null;
   int lo, hi;
   int init_min, init_max; /* cells in [init_min,init_max] hold defined values */
+  int max_ak;             /* M rows: max antidiagonal after extension (fast-overlap filter only) */
+  bool saw_oob;           /* some non-NULL value of this score was out of bounds (filter only) */
   int alo, ahi;           /* allocated index range */
   wf_offset_t* mem;       /* storage; cell k lives at mem[k - alo] */
   size_t cap;             /* elements allocated (modular rows own their buffer) */
@@ -135,6 +137,7 @@ typedef struct {
   wf_offset_t end_offset;
   int status;
   awo_stats_t* stats;
+  bool fast_overlap; /* exact pre-filter for the overlap search (CPU-baseline mode; same results) */
 } wf_aligner_t;
 
 struct awo_aligner {
@@ -318,6 +321,8 @@ static wavefront_t* allocate_output(wf_aligner_t* a, int comp, int score, int lo
   if (!wavefront_allocate(a, w, a->historic_min_lo, a->historic_max_hi)) return NULL;
   w->present = true;
   w->null = false;
+  w->max_ak = 0;
+  w->saw_oob = false;
   w->lo = lo;
   w->hi = hi;
   w->init_min = lo;
@@ -432,6 +437,20 @@ static bool wf_compute(wf_aligner_t* a, int score) {
       po_m[k] = max;
     }
   }
+  if (a->fast_overlap) { /* any non-NULL value out of bounds at this score? (the M candidate is the max of all) */
+    bool oob = false;
+    const wf_offset_t* pi1 = po_i1; const wf_offset_t* pd1 = po_d1;
+    for (int k = lo; k <= hi && !oob; ++k) {
+      const int hmax = MINI((int)tlen, (int)plen + k);
+      wf_offset_t mx = MAXI(pi1[k], pd1[k]);
+      if (p2) { mx = MAXI(mx, MAXI(out_i2->mem[k - out_i2->alo], out_d2->mem[k - out_d2->alo])); }
+      const wf_offset_t mm = pm_misms[k] + 1;
+      if (mm > mx) mx = mm;
+      if (mx >= 0 && mx > hmax) oob = true;
+    }
+    out_m->saw_oob = oob;
+    out_m->max_ak = 0;
+  }
   /* wavefront_compute_process_ends */
   wavefront_trim_ends(a, out_m);
   wavefront_trim_ends(a, out_i1);
@@ -511,6 +530,7 @@ static int wf_extend_end2end(wf_aligner_t* a, int score, int* max_ak) {
     if (max_antidiag < ad) max_antidiag = ad;
   }
   if (a->stats) a->stats->extend_bytes += bytes;
+  mwf->max_ak = max_antidiag;
   if (max_ak) *max_ak = max_antidiag;
   if (wf_termination_end2end(a, mwf, score)) {
     a->status = WF_STATUS_END_REACHED;
@@ -543,6 +563,8 @@ static bool wf_unialign_init(wf_aligner_t* a, int component_begin, int component
   wavefront_t* w = allocate_output(a, component_begin, 0, 0, 0);
   if (!w) return false;
   WF_AT(w, 0) = 0;
+  w->max_ak = 0;
+  w->saw_oob = false;
   return true;
 }
 
@@ -906,6 +928,11 @@ static void bialign_overlap(wf_aligner_t* a0, wf_aligner_t* a1, int score_0, int
     const int score_i = score_1 - i;
     if (score_i < 0) break;
     const int score_mod_i = score_i % max_score_scope;
+    if (a0->fast_overlap) { /* exact: every in-bounds cell of any component at a score is <= the extended M cell */
+      wavefront_t* m1 = present_or_null(a1, COMP_M, score_mod_i);
+      if (m1 == NULL) continue; /* null step: nothing to overlap with */
+      if (!mwf_0->saw_oob && !m1->saw_oob && mwf_0->max_ak + m1->max_ak < a0->plen + a0->tlen) continue;
+    }
     if (p2 && score_0 + score_i - a0->o2 < bp->score) {
       wavefront_t* d2wf_1 = present_or_null(a1, COMP_D2, score_mod_i);
       if (d2wf_0 != NULL && d2wf_1 != NULL)
@@ -1042,6 +1069,11 @@ awo_aligner_t* awo_aligner_new(const awo_penalties_t* pen) {
   aligner_init(&A->rev, pen, true);
   aligner_init(&A->sub, pen, false);
   return A;
+}
+
+void awo_aligner_set_fast_overlap(awo_aligner_t* A, int on) {
+  if (!A) return;
+  A->fwd.fast_overlap = A->rev.fast_overlap = on != 0;
 }
 
 void awo_aligner_delete(awo_aligner_t* A) {

@@ -67,6 +67,10 @@ typedef struct {
 typedef struct awo_aligner awo_aligner_t;
 awo_aligner_t* awo_aligner_new(const awo_penalties_t* pen);
 void awo_aligner_delete(awo_aligner_t* a);
+/* CPU-baseline mode: skip score pairs in the overlap search whose M-row antidiagonal maxima cannot
+ * reach plen + tlen (exact -- results are identical; tests/test_oracle.py checks it).  Off by default
+ * so the checker keeps WFA2's plain search. */
+void awo_aligner_set_fast_overlap(awo_aligner_t* a, int on);
 
 /*
  * One end-to-end alignment (pattern = query, text = target; alignment.rs:231).
@@ -108,6 +112,11 @@ double awo_all_pairs(const uint8_t* seqs, const uint64_t* offsets, int nseq,
                      const int32_t* pairs, int64_t npairs, const awo_penalties_t* pen,
                      int nthreads, awo_pair_result_t* results, awo_stats_t* stats_total,
                      uint64_t* paf_sink_bytes);
+/* same, with the exact overlap pre-filter enabled in every worker's aligner */
+double awo_all_pairs_fast(const uint8_t* seqs, const uint64_t* offsets, int nseq,
+                          const int32_t* pairs, int64_t npairs, const awo_penalties_t* pen,
+                          int nthreads, awo_pair_result_t* results, awo_stats_t* stats_total,
+                          uint64_t* paf_sink_bytes);
 
 #ifdef __cplusplus
 }

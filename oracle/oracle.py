@@ -73,10 +73,11 @@ def lib():
         L.awo_gotoh_penalty.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(Penalties)]
         L.awo_cigar_check.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int,
                                       C.POINTER(Penalties), C.POINTER(C.c_int64)]
-        L.awo_all_pairs.restype = C.c_double
-        L.awo_all_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
-                                    C.POINTER(Penalties), C.c_int, C.c_void_p, C.POINTER(Stats),
-                                    C.POINTER(C.c_uint64)]
+        for fn in (L.awo_all_pairs, L.awo_all_pairs_fast):
+            fn.restype = C.c_double
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(Penalties), C.c_int,
+                           C.c_void_p, C.POINTER(Stats), C.POINTER(C.c_uint64)]
+        L.awo_aligner_set_fast_overlap.argtypes = [C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -89,6 +90,10 @@ class Aligner:
         self._h = lib().awo_aligner_new(C.byref(self.pen))
         if not self._h:
             raise ValueError("penalties rejected (match must be 0, x>0, e>0)")
+
+    def set_fast_overlap(self, on):
+        """Exact pre-filter for the overlap search (CPU-baseline mode); results are identical."""
+        lib().awo_aligner_set_fast_overlap(self._h, int(bool(on)))
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -131,7 +136,7 @@ def cigar_check(cigar, pattern, text, scores):
     return rc, out.value
 
 
-def all_pairs(seqs, offsets, pairs, scores, nthreads=1, want_paf=False):
+def all_pairs(seqs, offsets, pairs, scores, nthreads=1, want_paf=False, fast_overlap=False):
     """Thread-pool all-pairs run. seqs: uint8 array (concatenated), offsets: uint64[n+1],
     pairs: int32[npairs,2]. Returns (seconds, results structured array, Stats, paf_bytes)."""
     pen = scores if isinstance(scores, Penalties) else Penalties.from_scores(scores)
@@ -142,7 +147,8 @@ def all_pairs(seqs, offsets, pairs, scores, nthreads=1, want_paf=False):
     assert res.dtype.itemsize == C.sizeof(PairResult)
     st = Stats()
     paf = C.c_uint64(0)
-    secs = lib().awo_all_pairs(seqs.ctypes.data, offsets.ctypes.data, len(offsets) - 1, pairs.ctypes.data,
+    fn = lib().awo_all_pairs_fast if fast_overlap else lib().awo_all_pairs
+    secs = fn(seqs.ctypes.data, offsets.ctypes.data, len(offsets) - 1, pairs.ctypes.data,
                                len(pairs), C.byref(pen), int(nthreads), res.ctypes.data, C.byref(st),
                                C.byref(paf) if want_paf else None)
     if secs < 0:

@@ -175,3 +175,35 @@ def test_bad_arguments(engine):
         engine.align_pairs(DEFAULT_2P, [(0, 2)])     # index out of range
     res, _ = engine.align_pairs(DEFAULT_2P, np.zeros((0, 2), dtype=np.int32))
     assert len(res) == 0
+
+
+def test_row_width_and_sequence_paths_agree(oracle):
+    """The kernel variants must be interchangeable: 16-bit vs forced 32-bit wavefront rows, 2-bit
+    packed LDS staging vs raw-byte probes from HBM -- all bit-exact against the oracle."""
+    from allwave_amd import ffi
+    rng = random.Random(4242)
+    seqs, pairs = [], []
+    for _ in range(60):
+        s, t = random_pair(rng, 2500)
+        seqs += [s, t]
+        pairs.append((len(seqs) - 2, len(seqs) - 1))
+    for flags in (0, ffi.AWV_F_FORCE_INT32, ffi.AWV_F_NO_PACKED_SEQ, ffi.AWV_F_FORCE_INT32 | ffi.AWV_F_NO_PACKED_SEQ):
+        e = ffi.Engine(flags=flags)
+        try:
+            for scores in (DEFAULT_2P, (0, 4, 6, 2)):
+                check_against_oracle(e, oracle, seqs, pairs, scores)
+        finally:
+            e.close()
+
+
+def test_long_sequences_use_32bit_rows(engine, oracle):
+    """Lengths >= 32760 select the int32 kernel and sequences too long for LDS staging at the top
+    levels (BASELINE config 4's regime, scaled down): 40 kbp at 2%, plus a length-mismatched pair."""
+    rng = random.Random(99)
+    a = rand_seq(rng, 40000)
+    b = mutate(a, 0.02, rng)
+    c = a[:9000]
+    seqs = [a, b, c]
+    check_against_oracle(engine, oracle, seqs, [(0, 1), (1, 0), (2, 1), (0, 2)], DEFAULT_2P)
+    st = engine.stats()
+    assert st.n_breakpoints > 10 and st.pairs_completed == 4

@@ -155,3 +155,15 @@ def test_all_pairs_driver(oracle):
         pen, ops = al.align(bytes(data[offs[a]:offs[a + 1]]), bytes(data[offs[b]:offs[b + 1]]))
         assert res["penalty"][i] == pen and res["cigar_len"][i] == len(ops)
         assert res["num_matches"][i] == ops.count(b"M")
+
+
+def test_fast_overlap_mode_is_identical(oracle):
+    """The CPU-baseline mode (exact antidiagonal pre-filter in the overlap search) must return the
+    same penalties and CIGARs as the plain WFA2-order search the checker uses."""
+    rng = random.Random(77)
+    for scores in (DEFAULT_2P, EDIT, (0, 3, 5, 1, 20, 1)):
+        plain, fast = oracle.Aligner(scores), oracle.Aligner(scores)
+        fast.set_fast_overlap(True)
+        for _ in range(60):
+            s, t = random_pair(rng, 3000)
+            assert plain.align(s, t) == fast.align(s, t)
