@@ -13,6 +13,7 @@ PKG = os.path.join(ROOT, "allwave_amd")
 CSRC = os.path.join(PKG, "csrc")
 HIP_LIB = os.path.join(PKG, "liballwave_hip.so")
 HOST_LIB = os.path.join(PKG, "liballwave_host.so")
+CLI_BIN = os.path.join(PKG, "allwave_hip")  # command-line driver (csrc/host/main.cpp)
 
 
 def _newer(target, sources):
@@ -46,13 +47,21 @@ def build_host(force=False, verbose=False):
     if not os.path.isdir(host_dir):
         return None
     srcs = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith((".cpp", ".hpp", ".h"))]
-    cpps = [s for s in srcs if s.endswith(".cpp")]
+    cpps = [s for s in srcs if s.endswith(".cpp") and not s.endswith("main.cpp")]
     if not cpps:
         return None
     if force or _newer(HOST_LIB, srcs + [os.path.join(ROOT, "include", "allwave_hip.h")]):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
                "-I" + host_dir, "-o", HOST_LIB] + cpps + ["-L" + PKG, "-lallwave_hip", "-Wl,-rpath,$ORIGIN",
                                                            "-Wl,-rpath-link,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    cli_src = os.path.join(host_dir, "main.cpp")
+    if os.path.exists(cli_src) and (force or _newer(CLI_BIN, srcs)):
+        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + host_dir, "-o", CLI_BIN,
+               cli_src, "-L" + PKG, "-lallwave_host", "-lallwave_hip", "-lz", "-Wl,-rpath,$ORIGIN",
+               "-Wl,-rpath-link,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

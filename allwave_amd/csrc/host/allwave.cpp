@@ -1,5 +1,6 @@
 // allwave.cpp -- host-side mirror of allwave's API over the C ABI (see allwave.hpp).
 #include "allwave.hpp"
+#include "planner.hpp"
 
 #include <algorithm>
 #include <climits>
@@ -220,14 +221,29 @@ AllPairIterator::AllPairIterator(const std::vector<Sequence>& sequences, Alignme
 
 AllPairIterator AllPairIterator::with_options(const std::vector<Sequence>& sequences, AlignmentParams params,
                                               bool exclude_self, bool use_mash_orientation, SparsificationStrategy s) {
-  if (s.kind != SparsificationStrategy::None)
-    throw AlignmentError("sparsification strategies other than None are not built yet (SURVEY.md 8f-3)");
   AllPairIterator it(sequences, std::move(params));
   it.exclude_self_ = exclude_self;
   if (!exclude_self) {  // iterator.rs:44-46
     it.pairs_.clear();
     for (size_t i = 0; i < sequences.size(); ++i)
       for (size_t j = 0; j < sequences.size(); ++j) it.pairs_.emplace_back(i, j);
+  }
+  switch (s.kind) {  // iterator.rs:49-79
+    case SparsificationStrategy::None: break;
+    case SparsificationStrategy::Random:
+      it.pairs_ = planner::apply_random_sparsification(std::move(it.pairs_), s.value, sequences);
+      break;
+    case SparsificationStrategy::Auto:
+      it.pairs_ = planner::apply_random_sparsification(std::move(it.pairs_),
+                                                      planner::compute_connectivity_probability(sequences.size(), 0.95), sequences);
+      break;
+    case SparsificationStrategy::Connectivity:
+      it.pairs_ = planner::apply_random_sparsification(std::move(it.pairs_),
+                                                      planner::compute_connectivity_probability(sequences.size(), s.value), sequences);
+      break;
+    case SparsificationStrategy::TreeSampling:
+      it.pairs_ = planner::extract_tree_pairs(sequences, s.k_nearest, s.k_farthest, s.random_fraction, s.kmer_size.value_or(15));
+      break;
   }
   it.orientation_ = use_mash_orientation ? Orientation::Mash : Orientation::Wfa;
   return it;
@@ -239,14 +255,14 @@ AllPairIterator& AllPairIterator::with_device(int device) { device_ = device; re
 
 void AllPairIterator::run(const std::function<void(int64_t, int64_t, const awv_result*, const uint8_t*,
                                                    const std::vector<uint8_t>&)>& batch_cb) {
-  if (orientation_ == Orientation::Mash)
-    throw AlignmentError("mash orientation is not built yet (SURVEY.md 8f-2): use Orientation::Wfa or ForwardOnly");
   EngineHolder eh(device_);
   upload(eh.e, sequences_);
   const int64_t n = (int64_t)pairs_.size();
   std::vector<uint8_t> is_rev((size_t)n, 0);
   std::vector<awv_pair> ap((size_t)n);
-  if (orientation_ == Orientation::Wfa) {
+  if (orientation_ == Orientation::Mash) {
+    is_rev = planner::orient_pairs_mash(sequences_, pairs_, 16);  // alignment.rs:69-94 (host threads)
+  } else if (orientation_ == Orientation::Wfa) {
     // determine_orientation_wfa (alignment.rs:157-175): align forward and reverse-complement with the
     // orientation params, compare #X+#I+#D; forward wins ties; a failed alignment counts as usize::MAX
     std::vector<awv_pair> op((size_t)2 * n);
@@ -393,4 +409,63 @@ AlignmentResult align_sequences(const std::vector<uint8_t>& pattern, const std::
 }
 
 }  // namespace wfa
+}  // namespace allwave
+
+namespace allwave {
+SparsificationStrategy SparsificationStrategy::parse(const std::string& s) {  // main.rs:136-203
+  SparsificationStrategy r;
+  auto to_double = [](const std::string& t, const char* msg) {
+    size_t used = 0;
+    double v = 0;
+    try { v = std::stod(t, &used); } catch (...) { throw std::invalid_argument(msg); }
+    if (used != t.size() || t.empty()) throw std::invalid_argument(msg);
+    return v;
+  };
+  auto to_usize = [](const std::string& t, const char* msg) {
+    if (t.empty() || t.find_first_not_of("0123456789") != std::string::npos) throw std::invalid_argument(msg);
+    return (size_t)std::stoull(t);
+  };
+  if (s == "none") return r;
+  if (s == "auto") { r.kind = Auto; return r; }
+  if (s.rfind("random:", 0) == 0) {
+    r.kind = Random;
+    r.value = to_double(s.substr(7), "Invalid random fraction");
+    if (r.value <= 0.0 || r.value > 1.0) throw std::invalid_argument("Random fraction must be between 0 and 1");
+    return r;
+  }
+  if (s.rfind("giant:", 0) == 0 || s.rfind("connectivity:", 0) == 0) {
+    const bool giant = s[0] == 'g';
+    r.kind = Connectivity;
+    r.value = to_double(s.substr(giant ? 6 : 13), giant ? "Invalid giant component probability" : "Invalid connectivity probability");
+    if (r.value <= 0.0 || r.value >= 1.0)
+      throw std::invalid_argument(giant ? "Giant component probability must be between 0 and 1" : "Connectivity probability must be between 0 and 1");
+    return r;
+  }
+  if (s.rfind("tree:", 0) == 0) {
+    std::vector<std::string> parts;
+    size_t pos = 5;
+    while (true) {
+      const size_t c = s.find(':', pos);
+      parts.push_back(s.substr(pos, c == std::string::npos ? std::string::npos : c - pos));
+      if (c == std::string::npos) break;
+      pos = c + 1;
+    }
+    if (parts.size() < 3 || parts.size() > 4)
+      throw std::invalid_argument("Invalid tree format. Use: tree:<k_nearest>:<k_farthest>:<random_fraction>[:<kmer_size>]");
+    r.kind = TreeSampling;
+    r.k_nearest = to_usize(parts[0], "Invalid k nearest count");
+    r.k_farthest = to_usize(parts[1], "Invalid k farthest count");
+    r.random_fraction = to_double(parts[2], "Invalid random fraction");
+    if (r.k_nearest == 0 && r.k_farthest == 0)
+      throw std::invalid_argument("At least one of k_nearest or k_farthest must be greater than 0");
+    if (!(r.random_fraction >= 0.0 && r.random_fraction <= 1.0)) throw std::invalid_argument("Random fraction must be between 0 and 1");
+    if (parts.size() == 4) {
+      const size_t k = to_usize(parts[3], "Invalid k-mer size");
+      if (k < 3 || k > 31) throw std::invalid_argument("K-mer size must be between 3 and 31");
+      r.kmer_size = k;
+    }
+    return r;
+  }
+  throw std::invalid_argument("Invalid sparsification strategy. Use: none, auto, giant:<probability>, random:<fraction>, or tree:<near>:<far>:<random>[:<kmer>]");
+}
 }  // namespace allwave

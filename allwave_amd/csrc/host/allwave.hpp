@@ -9,7 +9,7 @@
 //   cigar_bytes_to_string, reverse_complement, align_pair's result mapping       src/alignment.rs:25-66,178-190,347-376
 //   AllPairIterator (-p none enumeration, WFA orientation, callback streaming)   src/iterator.rs:12-253
 //   wfa::align_sequences / validate_cigar_alignment                              src/wfa.rs:105-258
-// Not mirrored this round (SURVEY.md 8f "next"): mash orientation, sparsifiers, the CLI.
+// Pair planning (mash orientation, sparsifiers, kNN/tree pairs) lives in planner.hpp; the CLI in main.cpp.
 #pragma once
 
 #include <cstdint>
@@ -54,9 +54,14 @@ struct AlignmentError : std::runtime_error {  // types.rs:121-131
   using std::runtime_error::runtime_error;
 };
 
-struct SparsificationStrategy {  // types.rs:78-95 (only None is implemented this round)
+struct SparsificationStrategy {  // types.rs:78-95
   enum Kind { None, Random, Auto, Connectivity, TreeSampling } kind = None;
-  double value = 0.0;
+  double value = 0.0;                     // Random(frac) / Connectivity(prob)
+  size_t k_nearest = 0, k_farthest = 0;   // TreeSampling(k_nearest, k_farthest, random_fraction, kmer_size)
+  double random_fraction = 0.0;
+  std::optional<size_t> kmer_size;
+  // the CLI's -p syntax (main.rs:136-203): none | auto | random:<f> | giant:<p> | connectivity:<p> | tree:<n>:<f>:<r>[:<k>]
+  static SparsificationStrategy parse(const std::string& s);  // throws std::invalid_argument with main.rs's messages
 };
 
 // lib.rs:116-153 -- throws std::invalid_argument with the reference's messages
@@ -75,7 +80,7 @@ void append_paf(std::string& out, const AlignmentResult& r, const uint8_t* ops, 
 enum class Orientation {
   Wfa,          // determine_orientation_wfa (alignment.rs:157-175): what AllPairIterator::new uses
   ForwardOnly,  // extension: skip orientation (all '+'); used when strands are known
-  Mash          // determine_orientation_mash (alignment.rs:69-154): SURVEY 8f-2, not built yet
+  Mash          // determine_orientation_mash (alignment.rs:69-154), hoisted to per-sequence sketches
 };
 
 using Callback = std::function<void(AlignmentResult&&)>;  // may throw: first error aborts the run

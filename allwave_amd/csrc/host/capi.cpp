@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "allwave.hpp"
+#include "planner.hpp"
 
 using namespace allwave;
 
@@ -79,11 +80,12 @@ int awh_format_paf(const char* qid, size_t qlen, const char* tid, size_t tlen, s
 }
 
 int awh_all_pairs_paf(int n, const char* const* ids, const uint8_t* bytes, const uint64_t* offs, const char* scores,
-                      int orientation, int exclude_self, int device, char** out, size_t* out_len, char* err, size_t cap) {
+                      const char* sparsification, int orientation, int exclude_self, int device, char** out, size_t* out_len,
+                      char* err, size_t cap) {
   try {
     const std::vector<Sequence> seqs = make_seqs(n, ids, bytes, offs);
     AllPairIterator it = AllPairIterator::with_options(seqs, parse_scores(scores), exclude_self != 0, orientation == 2,
-                                                      SparsificationStrategy{});
+                                                      SparsificationStrategy::parse(sparsification ? sparsification : "none"));
     it.with_orientation(orientation == 0 ? Orientation::ForwardOnly : orientation == 1 ? Orientation::Wfa : Orientation::Mash);
     it.with_device(device);
     std::string all;
@@ -139,6 +141,54 @@ int awh_validate_cigar(const uint8_t* cigar, size_t n, size_t qlen, size_t rlen,
   if (m.empty()) return 0;
   set_err(err, cap, m);
   return -1;
+}
+
+// ---- planner hooks (no GPU needed) ----
+uint64_t awh_siphash(const uint8_t* p, size_t n, uint64_t k0, uint64_t k1, int c, int d) { return planner::siphash(p, n, k0, k1, c, d); }
+uint64_t awh_hash_bytes(const uint8_t* p, size_t n) { return planner::default_hash_bytes(p, n); }
+uint64_t awh_hash_str(const char* s) { return planner::default_hash_str(s); }
+double awh_connectivity_probability(size_t n, double x) { return planner::compute_connectivity_probability(n, x); }
+
+// pair list of AllPairIterator::with_options(..., strategy) without aligning: out = malloc'ed (i, j) int64 pairs
+int awh_plan_pairs(int n, const char* const* ids, const uint8_t* bytes, const uint64_t* offs, const char* sparsification,
+                   int exclude_self, int64_t** out, size_t* npairs, char* err, size_t cap) {
+  try {
+    const std::vector<Sequence> seqs = make_seqs(n, ids, bytes, offs);
+    AllPairIterator it = AllPairIterator::with_options(seqs, AlignmentParams{}, exclude_self != 0, false,
+                                                      SparsificationStrategy::parse(sparsification));
+    const auto& p = it.get_pairs();
+    *out = (int64_t*)malloc(sizeof(int64_t) * 2 * (p.size() + 1));
+    for (size_t i = 0; i < p.size(); ++i) { (*out)[2 * i] = (int64_t)p[i].first; (*out)[2 * i + 1] = (int64_t)p[i].second; }
+    *npairs = p.size();
+    return 0;
+  } catch (const std::exception& e) { set_err(err, cap, e.what()); return -1; }
+}
+
+int awh_knn_graph(const double* dist, int n, int k, int farthest, int64_t** out, size_t* npairs) {
+  std::vector<std::vector<double>> d((size_t)n, std::vector<double>((size_t)n));
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) d[i][j] = dist[i * n + j];
+  const auto p = planner::build_knn_graph(d, (size_t)k, farthest != 0);
+  *out = (int64_t*)malloc(sizeof(int64_t) * 2 * (p.size() + 1));
+  for (size_t i = 0; i < p.size(); ++i) { (*out)[2 * i] = (int64_t)p[i].first; (*out)[2 * i + 1] = (int64_t)p[i].second; }
+  *npairs = p.size();
+  return 0;
+}
+
+int awh_mash_matrix(int n, const char* const* ids, const uint8_t* bytes, const uint64_t* offs, int k, double* out) {
+  const std::vector<Sequence> seqs = make_seqs(n, ids, bytes, offs);
+  const auto m = planner::compute_distance_matrix(seqs, (size_t)k, 1000);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) out[i * n + j] = m[i][j];
+  return 0;
+}
+
+int awh_orient_mash(int n, const char* const* ids, const uint8_t* bytes, const uint64_t* offs, const int64_t* pairs,
+                    size_t npairs, uint8_t* is_rev) {
+  const std::vector<Sequence> seqs = make_seqs(n, ids, bytes, offs);
+  std::vector<std::pair<size_t, size_t>> p(npairs);
+  for (size_t i = 0; i < npairs; ++i) p[i] = {(size_t)pairs[2 * i], (size_t)pairs[2 * i + 1]};
+  const auto r = planner::orient_pairs_mash(seqs, p, 8);
+  memcpy(is_rev, r.data(), npairs);
+  return 0;
 }
 
 void awh_free(void* p) { free(p); }

@@ -101,15 +101,15 @@ def _seq_args(ids, seqs):
     return cids, data, offs
 
 
-def all_pairs_paf(ids, seqs, scores, orientation="wfa", exclude_self=True, device=0):
-    """AllPairIterator (-p none) + alignment_to_paf per record; returns the list of PAF lines."""
+def all_pairs_paf(ids, seqs, scores, orientation="wfa", exclude_self=True, device=0, sparsification="none"):
+    """AllPairIterator + alignment_to_paf per record; returns the list of PAF lines."""
     cids, data, offs = _seq_args(ids, seqs)
     out = C.c_void_p()
     n = C.c_size_t(0)
     e = _err()
     rc = load().awh_all_pairs_paf(len(ids), cids, data.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p),
-                                  scores.encode(), ORIENT[orientation], int(exclude_self), device, C.byref(out),
-                                  C.byref(n), e, _CAP)
+                                  scores.encode(), sparsification.encode(), ORIENT[orientation], int(exclude_self),
+                                  device, C.byref(out), C.byref(n), e, _CAP)
     if rc != 0:
         raise HostError(e.value.decode())
     txt = C.string_at(out, n.value).decode()
@@ -147,3 +147,76 @@ def align_sequences(pattern, text, penalties, mode, device=0):
         raise HostError(e.value.decode())
     return dict(score=score.value, cigar=cig.value.decode(), matches=counts[0], mismatches=counts[1],
                 insertions=counts[2], deletions=counts[3], alignment_length=counts[4])
+
+
+# ---- planner (host-only, no GPU) ---------------------------------------------------------------
+def siphash(data, k0=0, k1=0, c=1, d=3):
+    L = load()
+    L.awh_siphash.restype = C.c_uint64
+    data = bytes(data)
+    return L.awh_siphash(data, C.c_size_t(len(data)), C.c_uint64(k0), C.c_uint64(k1), c, d)
+
+
+def hash_bytes(data):
+    """Rust: DefaultHasher over a `[u8]` (length prefix + bytes), as hash_kmer does."""
+    L = load()
+    L.awh_hash_bytes.restype = C.c_uint64
+    data = bytes(data)
+    return L.awh_hash_bytes(data, C.c_size_t(len(data)))
+
+
+def hash_str(s):
+    """Rust: DefaultHasher over a `str` (bytes + 0xFF), as the pair sparsifier does."""
+    L = load()
+    L.awh_hash_str.restype = C.c_uint64
+    return L.awh_hash_str(s.encode())
+
+
+def connectivity_probability(n, x):
+    L = load()
+    L.awh_connectivity_probability.restype = C.c_double
+    return L.awh_connectivity_probability(C.c_size_t(n), C.c_double(x))
+
+
+def _pairs_out(out, n):
+    a = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int64)), shape=(max(n, 1) * 2,))[:2 * n].reshape(n, 2).copy()
+    load().awh_free(out)
+    return [tuple(int(v) for v in r) for r in a]
+
+
+def plan_pairs(ids, seqs, sparsification, exclude_self=True):
+    """Pair list AllPairIterator::with_options would align (iterator.rs:30-92)."""
+    cids, data, offs = _seq_args(ids, seqs)
+    out = C.c_void_p()
+    n = C.c_size_t(0)
+    e = _err()
+    rc = load().awh_plan_pairs(len(ids), cids, data.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p),
+                               sparsification.encode(), int(exclude_self), C.byref(out), C.byref(n), e, _CAP)
+    if rc != 0:
+        raise ValueError(e.value.decode())
+    return _pairs_out(out, n.value)
+
+
+def knn_graph(dist, k, farthest=False):
+    d = np.ascontiguousarray(dist, dtype=np.float64)
+    out = C.c_void_p()
+    n = C.c_size_t(0)
+    load().awh_knn_graph(d.ctypes.data_as(C.c_void_p), len(d), int(k), int(farthest), C.byref(out), C.byref(n))
+    return _pairs_out(out, n.value)
+
+
+def mash_matrix(ids, seqs, k=15):
+    cids, data, offs = _seq_args(ids, seqs)
+    out = np.zeros((len(ids), len(ids)), dtype=np.float64)
+    load().awh_mash_matrix(len(ids), cids, data.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), int(k),
+                           out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def orient_mash(ids, seqs, pairs):
+    cids, data, offs = _seq_args(ids, seqs)
+    p = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+    out = np.zeros(len(p), dtype=np.uint8)
+    load().awh_orient_mash(len(ids), cids, data.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p),
+                           p.ctypes.data_as(C.c_void_p), C.c_size_t(len(p)), out.ctypes.data_as(C.c_void_p))
+    return [bool(x) for x in out]

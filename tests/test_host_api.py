@@ -126,6 +126,22 @@ def test_wfa_align_sequences(host, oracle):
 
 
 @pytest.mark.gpu
-def test_mash_orientation_not_built(host):
-    with pytest.raises(host.HostError, match="8f-2"):
-        host.all_pairs_paf(["a", "b"], [b"ACGT" * 10, b"ACGA" * 10], "0,1,1,1", orientation="mash")
+def test_mash_orientation_agrees_with_wfa(host, oracle):
+    """tests/integration_tests.rs:866-1033: mash and WFA orientation agree with the ground truth on
+    forward / reverse-complemented queries at several mutation rates (the CLI default is mash)."""
+    rng = random.Random(12345)
+    seqs, ids, truth = [], [], []
+    for n, d, rev in ((1000, 0.0, False), (1000, 0.01, False), (1000, 0.01, True), (1000, 0.05, False),
+                      (1000, 0.05, True), (100, 0.0, True), (5000, 0.001, False)):
+        ref = rand_seq(rng, n)
+        q = mutate(ref, d, rng)
+        if rev:
+            q = host.reverse_complement(q)
+        ids += ["ref%d" % len(truth), "qry%d" % len(truth)]
+        seqs += [ref, q]
+        truth.append(rev)
+    for orient in ("mash", "wfa"):
+        lines = host.all_pairs_paf(ids, seqs, "0,5,8,2,24,1", orientation=orient)
+        by = {(l.split("\t")[0], l.split("\t")[5]): l.split("\t")[4] for l in lines}
+        for i, rev in enumerate(truth):
+            assert by[("qry%d" % i, "ref%d" % i)] == ("-" if rev else "+"), (orient, i)
