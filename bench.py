@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paf", action="store_true", help="skip the end-to-end PAF formatting figure")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="debug: all ranks share GPU 0 and synchronise over gloo (multi-rank plumbing on a 1-GPU box)")
     args = ap.parse_args()
 
     import numpy as np
@@ -61,8 +63,11 @@ def main():
     rank, local_rank, world = D.env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = D.init(backend="nccl") if world > 1 else None  # RCCL: only the barrier + the final reduction
+    # RCCL (backend "nccl") carries only the timing barrier and the final reduction of counters
+    dist = D.init(backend="gloo" if args.rehearse_one_gpu else "nccl") if world > 1 else None
 
     from allwave_amd import ffi, synth
 
