@@ -525,7 +525,15 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
   const int colLo = lo - kmin, colHi = hi - kmin;
   int lane_maxak = 0;
   bool lane_oob = false;
-  for (int cb = (colLo & ~(WSPAN - 1)) + WSPAN * wave; cb <= colHi; cb += WSPAN * (WG / 64)) {
+  // One wave per pair: the wave's 256-column window starts at the row's first column (rounded to a
+  // lane vector), so a row of width W takes ceil(W / 256) iterations wherever it lies.  Lanes
+  // [0, split) of every iteration fall in absolute chunk cb >> 8, the rest in the next one (the
+  // overlap filter keeps its maxima per absolute chunk).  Several waves per pair keep whole chunks.
+  constexpr bool ROW_ALIGNED = (WG == 64);
+  const int cb_first = ROW_ALIGNED ? (colLo & ~(VEC - 1)) : (colLo & ~(WSPAN - 1)) + WSPAN * wave;
+  const int split = (WSPAN - (cb_first & (WSPAN - 1))) / VEC;  // 1..64, constant over the row
+  int carry_ak = 0, last_cb = cb_first;
+  for (int cb = cb_first; cb <= colHi; cb += WSPAN * (WG / 64)) {
     const int c0 = cb + lane * VEC;
     const int k0 = c0 + kmin;
     const int voff = (c0 - 1) * ESZ;  // byte offset of diagonal k0-1; shifts are immediates
@@ -560,67 +568,153 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_LOAD, tc0);
     const unsigned long long tc1 = PROF_NOW();
-    int32_t vMx[VEC], vO1l[VEC], vO1r[VEC], vI1[VEC], vD1[VEC], vO2l[VEC], vO2r[VEC], vI2[VEC], vD2[VEC];
-    unpack_raw<OffT>(rMx, vMx);
-    unpack_raw<OffT>(rO1l, vO1l);
-    unpack_raw<OffT>(rO1r, vO1r);
-    unpack_raw<OffT>(rI1, vI1);
-    unpack_raw<OffT>(rD1, vD1);
-    if (P2) {
-      unpack_raw<OffT>(rO2l, vO2l);
-      unpack_raw<OffT>(rO2r, vO2r);
-      unpack_raw<OffT>(rI2, vI2);
-      unpack_raw<OffT>(rD2, vD2);
-    }
-    if (!interior) {  // edge waves (or a source row absent/narrower): mask by each row's own range
-      auto mask = [&](const RowMeta& mm, int shift, int32_t (&v)[VEC]) {
+    int32_t m[VEC];
+    bool packed_done = false;
+#ifndef AWV_NO_PACKED_DP
+    if constexpr (sizeof(OffT) == 2) {
+      {
+        // ---- 16-bit rows: the DP runs on packed pairs (v_pk_max_i16 / v_pk_add_u16 / v_pk_min_i16),
+        // two diagonals per instruction.  All values fit 16 bits (offsets <= tlen + 1, NULL16 = -16384,
+        // at most +1 per step before the store re-canonicalises), so the ordering and results are
+        // those of the 32-bit arithmetic used for 32-bit rows below.
+        typedef short s2 __attribute__((ext_vector_type(2)));
+        auto as2 = [](unsigned w) { return __builtin_bit_cast(s2, w); };
+        auto asu = [](s2 v) { return __builtin_bit_cast(unsigned, v); };
+        const s2 one = {1, 1}, nullv = {(short)NULL16, (short)NULL16};
+        if (!interior) {  // edge waves (or a source row absent/narrower): NULL out what lies outside each row's range
+          auto mask = [&](const RowMeta& mm, int shift, RawVec<OffT>& v) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          const int kk = k0 + shift + j;
-          v[j] = (kk >= mm.lo && kk <= mm.hi) ? v[j] : OFF_NULL;
+            for (int r = 0; r < 2; ++r) {
+              const int ka = k0 + shift + 2 * r;
+              const unsigned keep = ((ka >= mm.lo && ka <= mm.hi) ? 0x0000FFFFu : 0u) |
+                                    ((ka + 1 >= mm.lo && ka + 1 <= mm.hi) ? 0xFFFF0000u : 0u);
+              v.w[r] = (v.w[r] & keep) | (asu(nullv) & ~keep);
+            }
+          };
+          mask(pl.src[0], 0, rMx);
+          mask(pl.src[1], -1, rO1l);
+          mask(pl.src[1], +1, rO1r);
+          mask(pl.src[2], -1, rI1);
+          mask(pl.src[3], +1, rD1);
+          if (P2) {
+            mask(pl.src[4], -1, rO2l);
+            mask(pl.src[4], +1, rO2r);
+            mask(pl.src[5], -1, rI2);
+            mask(pl.src[6], +1, rD2);
+          }
         }
-      };
-      mask(pl.src[0], 0, vMx);
-      mask(pl.src[1], -1, vO1l);
-      mask(pl.src[1], +1, vO1r);
-      mask(pl.src[2], -1, vI1);
-      mask(pl.src[3], +1, vD1);
-      if (P2) {
-        mask(pl.src[4], -1, vO2l);
-        mask(pl.src[4], +1, vO2r);
-        mask(pl.src[5], -1, vI2);
-        mask(pl.src[6], +1, vD2);
-      }
-    }
-    int32_t m[VEC], ins1[VEC], del1[VEC], ins2[VEC], del2[VEC];
+        const short tl1 = (short)(tlen + 1);
+        const s2 tlen1 = {tl1, tl1};
+        auto canon = [&](s2 v) {  // v < 0 ? NULL16 : min(v, tlen + 1)   (what buf_store_vec does per element)
+          const s2 c = __builtin_elementwise_min(v, tlen1);
+          const s2 neg = v >> 15;  // 0xFFFF where negative
+          return (neg & nullv) | (~neg & c);
+        };
+        RawVec<OffT> oI1, oD1, oI2, oD2;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const int k = k0 + j;
-      ins1[j] = max(vO1l[j], vI1[j]) + 1;
-      del1[j] = max(vO1r[j], vD1[j]);
-      int32_t ins = ins1[j], del = del1[j];
-      if (P2) {
-        ins2[j] = max(vO2l[j], vI2[j]) + 1;
-        del2[j] = max(vO2r[j], vD2[j]);
-        ins = max(ins, ins2[j]);
-        del = max(del, del2[j]);
-      } else {
-        ins2[j] = del2[j] = OFF_NULL;
+        for (int r = 0; r < 2; ++r) {
+          const s2 ins1 = __builtin_elementwise_max(as2(rO1l.w[r]), as2(rI1.w[r])) + one;
+          const s2 del1 = __builtin_elementwise_max(as2(rO1r.w[r]), as2(rD1.w[r]));
+          s2 ins = ins1, del = del1;
+          oI1.w[r] = asu(canon(ins1));
+          oD1.w[r] = asu(canon(del1));
+          if (P2) {
+            const s2 ins2 = __builtin_elementwise_max(as2(rO2l.w[r]), as2(rI2.w[r])) + one;
+            const s2 del2 = __builtin_elementwise_max(as2(rO2r.w[r]), as2(rD2.w[r]));
+            ins = __builtin_elementwise_max(ins, ins2);
+            del = __builtin_elementwise_max(del, del2);
+            oI2.w[r] = asu(canon(ins2));
+            oD2.w[r] = asu(canon(del2));
+          }
+          const s2 mm = __builtin_elementwise_max(del, __builtin_elementwise_max(as2(rMx.w[r]) + one, ins));
+          const int ka = k0 + 2 * r;
+          const s2 hmax = {(short)max(min(tlen, plen + ka), -1), (short)max(min(tlen, plen + ka + 1), -1)};
+          const s2 over = (__builtin_elementwise_min(mm, hmax) - mm) >> 15;  // 0xFFFF where mm > hmax
+          const s2 neg = mm >> 15;
+          lane_oob |= asu(over & ~neg) != 0u;  // a non-NULL value of the cell is out of bounds
+          const s2 bad = over | neg;
+          const s2 mv = (bad & nullv) | (~bad & mm);
+          m[2 * r] = (int)mv[0] < 0 ? OFF_NULL : (int)mv[0];
+          m[2 * r + 1] = (int)mv[1] < 0 ? OFF_NULL : (int)mv[1];
+        }
+        if (lane_on) {
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          auto st = [&](int soff, const RawVec<OffT>& v) {
+            u32x2 raw;
+            raw[0] = v.w[0];
+            raw[1] = v.w[1];
+            __builtin_amdgcn_raw_buffer_store_b64(raw, rs, voff + ESZ, soff, 0);
+          };
+          st(tI1, oI1);
+          st(tD1, oD1);
+          if (P2) { st(tI2, oI2); st(tD2, oD2); }
+        }
+        packed_done = true;
       }
-      int32_t mm = max(del, max(vMx[j] + 1, ins));
-      // every value is <= mm, so nothing is out of bounds high unless mm is; low (v > plen) is per value
-      // in-bounds <=> 0 <= value <= hmax.  mm is the max of the cell's five values, so "some
-      // non-NULL value of this cell is out of bounds" <=> mm > hmax (any negative is a NULL(+n)).
-      const int hmax = max(min(tlen, plen + k), -1);
-      lane_oob |= mm > hmax;
-      m[j] = (mm > hmax || mm < 0) ? OFF_NULL : mm;
     }
-    if (lane_on) {
-      buf_store_vec<OffT>(rs, voff + ESZ, tI1, ins1, tlen);
-      buf_store_vec<OffT>(rs, voff + ESZ, tD1, del1, tlen);
+#endif
+    if (!packed_done) {
+      int32_t vMx[VEC], vO1l[VEC], vO1r[VEC], vI1[VEC], vD1[VEC], vO2l[VEC], vO2r[VEC], vI2[VEC], vD2[VEC];
+      unpack_raw<OffT>(rMx, vMx);
+      unpack_raw<OffT>(rO1l, vO1l);
+      unpack_raw<OffT>(rO1r, vO1r);
+      unpack_raw<OffT>(rI1, vI1);
+      unpack_raw<OffT>(rD1, vD1);
       if (P2) {
-        buf_store_vec<OffT>(rs, voff + ESZ, tI2, ins2, tlen);
-        buf_store_vec<OffT>(rs, voff + ESZ, tD2, del2, tlen);
+        unpack_raw<OffT>(rO2l, vO2l);
+        unpack_raw<OffT>(rO2r, vO2r);
+        unpack_raw<OffT>(rI2, vI2);
+        unpack_raw<OffT>(rD2, vD2);
+      }
+      if (!interior) {  // edge waves (or a source row absent/narrower): mask by each row's own range
+        auto mask = [&](const RowMeta& mm, int shift, int32_t (&v)[VEC]) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const int kk = k0 + shift + j;
+            v[j] = (kk >= mm.lo && kk <= mm.hi) ? v[j] : OFF_NULL;
+          }
+        };
+        mask(pl.src[0], 0, vMx);
+        mask(pl.src[1], -1, vO1l);
+        mask(pl.src[1], +1, vO1r);
+        mask(pl.src[2], -1, vI1);
+        mask(pl.src[3], +1, vD1);
+        if (P2) {
+          mask(pl.src[4], -1, vO2l);
+          mask(pl.src[4], +1, vO2r);
+          mask(pl.src[5], -1, vI2);
+          mask(pl.src[6], +1, vD2);
+        }
+      }
+      int32_t ins1[VEC], del1[VEC], ins2[VEC], del2[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const int k = k0 + j;
+        ins1[j] = max(vO1l[j], vI1[j]) + 1;
+        del1[j] = max(vO1r[j], vD1[j]);
+        int32_t ins = ins1[j], del = del1[j];
+        if (P2) {
+          ins2[j] = max(vO2l[j], vI2[j]) + 1;
+          del2[j] = max(vO2r[j], vD2[j]);
+          ins = max(ins, ins2[j]);
+          del = max(del, del2[j]);
+        } else {
+          ins2[j] = del2[j] = OFF_NULL;
+        }
+        const int32_t mm = max(del, max(vMx[j] + 1, ins));
+        // in-bounds <=> 0 <= value <= hmax.  mm is the max of the cell's five values, so "some
+        // non-NULL value of this cell is out of bounds" <=> mm > hmax (any negative is a NULL(+n)).
+        const int hmax = max(min(tlen, plen + k), -1);
+        lane_oob |= mm > hmax;
+        m[j] = (mm > hmax || mm < 0) ? OFF_NULL : mm;
+      }
+      if (lane_on) {
+        buf_store_vec<OffT>(rs, voff + ESZ, tI1, ins1, tlen);
+        buf_store_vec<OffT>(rs, voff + ESZ, tD1, del1, tlen);
+        if (P2) {
+          buf_store_vec<OffT>(rs, voff + ESZ, tI2, ins2, tlen);
+          buf_store_vec<OffT>(rs, voff + ESZ, tD2, del2, tlen);
+        }
       }
     }
     PROF_DRAIN();
@@ -683,10 +777,20 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
       if (m[j] >= 0) it_maxak = max(it_maxak, 2 * m[j] - (k0 + j));
-    if (!BASE) {  // chunk maximum for the overlap filter: this wave-iteration is exactly one 256-column chunk
-      const int cmax = wave_max_i32(it_maxak);
-      if (lane == 0) lds.chunk_ak[((size_t)dir * kp.ring + (score & (kp.ring - 1))) * kp.chunks_cap + (cb >> 8)] = cmax;
-      lane_maxak = max(lane_maxak, cmax);
+    if (!BASE) {  // chunk maxima for the overlap filter
+      int* ck = lds.chunk_ak + ((size_t)dir * kp.ring + (score & (kp.ring - 1))) * kp.chunks_cap;
+      if (split == 64) {  // this wave-iteration is exactly one absolute chunk
+        const int cmax = wave_max_i32(it_maxak);
+        if (lane == 0) ck[cb >> 8] = cmax;
+        lane_maxak = max(lane_maxak, cmax);
+      } else {
+        const int lowmax = wave_max_i32(lane < split ? it_maxak : 0);
+        const int upmax = wave_max_i32(lane < split ? 0 : it_maxak);
+        if (lane == 0) ck[cb >> 8] = max(carry_ak, lowmax);
+        carry_ak = upmax;
+        last_cb = cb;
+        lane_maxak = max(lane_maxak, max(lowmax, upmax));
+      }
     } else {
       lane_maxak = max(lane_maxak, it_maxak);
     }
@@ -695,6 +799,8 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     PROF_ADD_L(STAT_T_CR_STORE, tc3);
   }
   const unsigned long long tc4 = PROF_NOW();
+  if (!BASE && split != 64 && lane == 0)  // upper part of the last window
+    lds.chunk_ak[((size_t)dir * kp.ring + (score & (kp.ring - 1))) * kp.chunks_cap + (last_cb >> 8) + 1] = carry_ak;
   const int wmax = BASE ? wave_max_i32(lane_maxak) : lane_maxak;  // (already wave-uniform per chunk otherwise)
   const bool woob = __any(lane_oob);
   if (lane == 0) {
