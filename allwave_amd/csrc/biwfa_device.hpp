@@ -1112,16 +1112,25 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
   // exact pre-filter: an overlap needs antidiag0 + antidiag1 >= plen + tlen on some diagonal;
   // every in-bounds cell of any component at score s is <= the (extended) M cell, so the rows'
   // max M antidiagonals bound it unless an out-of-bounds value was seen (oob).
-  auto group_pass = [&](int si) {
-    const int slot1 = si & rmask;
-    return oob0 || uni(lds.bi_oob[(d1) * kp.ring + (slot1)]) || (A0 + uni(lds.bi_A[(d1) * kp.ring + (slot1)]) >= L);
+  // Evaluated for all candidate scores at once: lane i looks at score s1 - i (64 per block).
+  const int gmax = P2 ? max(pn.o1, pn.o2) : pn.o1;
+  auto group_mask = [&](int ib) -> uint64_t {
+    const int i = ib + lane, si = s1 - i;
+    bool ok = false;
+    if (i < pn.scope && si >= 0) {
+      const int slot1 = si & rmask;
+      ok = oob0 || lds.bi_oob[d1 * kp.ring + slot1] || (A0 + lds.bi_A[d1 * kp.ring + slot1] >= L);
+    }
+    return __ballot(ok);
   };
   bool any = false;
-  for (int i = 0; i < pn.scope; ++i) {
-    const int si = s1 - i;
-    if (si < 0) break;
-    if (!group_pass(si)) continue;
-    if (s0 + si - (P2 ? max(pn.o1, pn.o2) : pn.o1) < bp.score) { any = true; break; }
+  for (int ib = 0; ib < pn.scope && !any; ib += 64) {
+    uint64_t gm = group_mask(ib);
+    while (gm) {
+      const int i = ib + (int)__builtin_ctzll(gm);
+      gm &= gm - 1;
+      if (s0 + (s1 - i) - gmax < bp.score) { any = true; break; }
+    }
   }
   if (!any) return;
   for (int i = tid; i < pn.scope * NCOMP; i += WG) lds.firstk[i] = INT_MAX;
@@ -1194,17 +1203,20 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
       }
     }
   };
-  for (int i = 0; i < pn.scope; ++i) {
-    const int si = s1 - i;
-    if (si < 0) break;
-    if (!group_pass(si)) continue;
-    const bool w2 = P2 && s0 + si - pn.o2 < bp.score, w1 = s0 + si - pn.o1 < bp.score, w0 = s0 + si < bp.score;
-    if (!(w2 || w1 || w0)) continue;
-    const uint64_t cmask = chunk_mask(si);
-    if (cmask == 0) continue;
-    if (w2) { scan(C_D2, i, si, cmask); scan(C_I2, i, si, cmask); }
-    if (w1) { scan(C_D1, i, si, cmask); scan(C_I1, i, si, cmask); }
-    if (w0) scan(C_M, i, si, cmask);
+  for (int ib = 0; ib < pn.scope; ib += 64) {
+    uint64_t gm = group_mask(ib);
+    while (gm) {
+      const int i = ib + (int)__builtin_ctzll(gm);
+      gm &= gm - 1;
+      const int si = s1 - i;
+      const bool w2 = P2 && s0 + si - pn.o2 < bp.score, w1 = s0 + si - pn.o1 < bp.score, w0 = s0 + si < bp.score;
+      if (!(w2 || w1 || w0)) continue;
+      const uint64_t cmask = chunk_mask(si);
+      if (cmask == 0) continue;
+      if (w2) { scan(C_D2, i, si, cmask); scan(C_I2, i, si, cmask); }
+      if (w1) { scan(C_D1, i, si, cmask); scan(C_I1, i, si, cmask); }
+      if (w0) scan(C_M, i, si, cmask);
+    }
   }
   __syncthreads();
   // stage 2: replay in WFA2's order (per i: D2, I2, D1, I1, M; first k ascending)
@@ -1220,14 +1232,17 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
     bp.score = s0 + si - gap_open;
     bp.comp = c;
   };
-  for (int i = 0; i < pn.scope; ++i) {
-    const int si = s1 - i;
-    if (si < 0) break;
-    if (!group_pass(si)) continue;
-    if (P2 && s0 + si - pn.o2 < bp.score) { apply(C_D2, i, si, pn.o2); apply(C_I2, i, si, pn.o2); }
-    if (s0 + si - pn.o1 < bp.score) { apply(C_D1, i, si, pn.o1); apply(C_I1, i, si, pn.o1); }
-    if (s0 + si >= bp.score) continue;
-    apply(C_M, i, si, 0);
+  for (int ib = 0; ib < pn.scope; ib += 64) {
+    uint64_t gm = group_mask(ib);
+    while (gm) {
+      const int i = ib + (int)__builtin_ctzll(gm);
+      gm &= gm - 1;
+      const int si = s1 - i;
+      if (P2 && s0 + si - pn.o2 < bp.score) { apply(C_D2, i, si, pn.o2); apply(C_I2, i, si, pn.o2); }
+      if (s0 + si - pn.o1 < bp.score) { apply(C_D1, i, si, pn.o1); apply(C_I1, i, si, pn.o1); }
+      if (s0 + si >= bp.score) continue;
+      apply(C_M, i, si, 0);
+    }
   }
   __syncthreads();  // firstk is rewritten by the next call
 }
