@@ -40,7 +40,7 @@ struct DevBuf {
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
-    size_t want = n + n / 8 + 64;
+    size_t want = n + std::min<size_t>(n / 8, (size_t)64 << 20) + 64;  // growth slack, bounded for the big arenas
     hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
     if (e != hipSuccess) {
       want = n;
@@ -282,38 +282,69 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       maxlen = std::max(maxlen, std::max(ql, tl));
       ++n;
     }
-    int wcap = ((maxsum + 9 + 256 + 2 * COL_PAD) + 255) & ~255;
-    if (const char* env = getenv("AWV_WCAP_MAX")) wcap = std::min(wcap, std::max(2048, atoi(env)));  // experiment knob
-    int nslots = (int)std::min<int64_t>(nslots_cfg, n);
+    // Dispatch order: workgroups take pairs from a shared cursor, so the most expensive pairs go
+    // first (longest-processing-time-first; the work of a pair grows with the square of its score,
+    // estimated here from the lengths and the gap a length difference forces).  Results and CIGARs
+    // keep their caller-order slots through the index map.  Equal-cost batches keep caller order.
+    std::vector<int64_t> amap;  // dispatch index -> batch index (empty = identity)
+    {
+      std::vector<int64_t> order((size_t)n);
+      std::vector<uint64_t> cost((size_t)n);
+      bool uniform = true;
+      for (int64_t i = 0; i < n; ++i) {
+        order[(size_t)i] = i;
+        const int64_t ql = s.len[hq[(size_t)i]], tl = s.len[ht[(size_t)i]];
+        cost[(size_t)i] = (uint64_t)(ql + tl + 4 * std::llabs(ql - tl));
+        uniform = uniform && cost[(size_t)i] == cost[0];
+      }
+      if (!uniform) {
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return cost[(size_t)a] > cost[(size_t)b]; });
+        std::vector<int32_t> q2((size_t)n), t2((size_t)n), rc2((size_t)n);
+        std::vector<uint64_t> off2((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+          const size_t o = (size_t)order[(size_t)i];
+          q2[(size_t)i] = hq[o]; t2[(size_t)i] = ht[o]; rc2[(size_t)i] = hrc[o]; off2[(size_t)i] = hoff[o];
+        }
+        hq.swap(q2); ht.swap(t2); hrc.swap(rc2); hoff.swap(off2);
+        amap.swap(order);
+      }
+    }
+    const int wcap_full = ((maxsum + 9 + 256 + 2 * COL_PAD) + 255) & ~255;
+    const int nslots_want = (int)std::min<int64_t>(nslots_cfg, n);
     // 16-bit wavefront rows whenever every offset fits (halves the HBM/L2 traffic of the rings)
-    // sequence staging: what the largest pair needs, within a 40 KB-per-workgroup LDS budget
-    // (4 workgroups per CU of 160 KB); sub-problems that do not fit read global memory instead
     const bool narrow = maxlen < 32760 && !(e->cfg.flags & AWV_F_FORCE_INT32);
     const size_t esz = narrow ? 2 : 4;
     // dynamic LDS = ring metadata (16-bit entries with 16-bit rows) + staging of the 2-bit packed
-    // sequences: what the largest pair needs, within 160 KB / (16 waves per CU) per workgroup
+    // sequences: what the largest pair needs, within 160 KB / (16 waves per CU) per workgroup;
+    // sub-problems that do not fit read global memory instead
     const size_t lds_meta = lds_meta_bytes(narrow ? sizeof(RowMeta16) : sizeof(RowMeta));
     const size_t seq_need = ((((size_t)maxlen + 15) / 16 + 2) * 2 + 10) * 4;
     const size_t lds_budget = (size_t)(160 * 1024 / (1024 / WG)) - 2048;
     size_t lds_seq = (e->cfg.flags & AWV_F_NO_PACKED_SEQ) ? 0 : (lds_meta < lds_budget ? std::min(seq_need, lds_budget - lds_meta) : 0);
     lds_seq &= ~(size_t)15;
     const size_t dyn_lds = lds_meta + lds_seq;
-    const size_t ring_stride = (size_t)2 * NCOMP * ring * wcap * esz;
     const size_t hist_rows = ((size_t)(sb_cap + 1) * NCOMP * wb_cap * esz + 63) & ~(size_t)63;
     const size_t hist_stride = hist_rows + (((size_t)(sb_cap + 1) * NCOMP * sizeof(RowMeta) + 63) & ~(size_t)63);
-    const size_t ev_stride = (size_t)wcap;
-    const int chunks_cap = wcap / 256 + 2;
-    const size_t chunk_stride = (size_t)2 * ring * chunks_cap;
-    {  // keep the per-workgroup arenas inside the scratch budget (default 160 GiB of the 288 GB HBM)
-      const size_t budget = e->cfg.max_scratch_bytes > 0 ? (size_t)e->cfg.max_scratch_bytes : (size_t)160 << 30;
-      const size_t per_slot = ring_stride + hist_stride + ev_stride * sizeof(uint32_t) + chunk_stride * sizeof(int);
-      const size_t fit = std::max<size_t>(1, budget / per_slot);
-      if ((size_t)nslots > fit) nslots = (int)fit;
+    // per-workgroup arenas as a function of the row capacity (columns)
+    const size_t budget = e->cfg.max_scratch_bytes > 0 ? (size_t)e->cfg.max_scratch_bytes : (size_t)160 << 30;
+    auto per_slot = [&](int wc) {
+      return (size_t)2 * NCOMP * ring * wc * esz + hist_stride + (size_t)wc * sizeof(uint32_t) +
+             (size_t)2 * ring * (wc / 256 + 2) * sizeof(int);
+    };
+    // Row capacity of the first attempt.  A wavefront at score s spans at most ~2 s / min(e) diagonals,
+    // far fewer than plen + tlen for similar sequences; when full-width rows would not leave room for
+    // every workgroup's arenas (long sequences), start with the widest rows that do and re-run only
+    // the pairs whose wavefronts outgrow them (status CAPACITY) with wider rows.
+    int wcap = wcap_full;
+    if (per_slot(wcap_full) * (size_t)nslots_want > budget) {
+      const size_t fixed = hist_stride + 2 * (size_t)2 * ring * sizeof(int);
+      const size_t per_col = (size_t)2 * NCOMP * ring * esz + sizeof(uint32_t) + (size_t)2 * ring * sizeof(int) / 256 + 1;
+      const size_t share = budget / (size_t)nslots_want;
+      long long wc = share > fixed ? (long long)((share - fixed) / per_col) : 0;
+      wc = std::max<long long>(wc & ~255LL, 8192);
+      wcap = (int)std::min<long long>(wcap_full, wc);
     }
-    if (int rc = e->ring_mem.reserve(ring_stride * nslots)) return rc;
-    if (int rc = e->hist_mem.reserve(hist_stride * nslots)) return rc;
-    if (int rc = e->ev_mem.reserve(ev_stride * nslots)) return rc;
-    if (int rc = e->chunk_mem.reserve(chunk_stride * nslots)) return rc;
+    if (const char* env = getenv("AWV_WCAP_MAX")) wcap = std::min(wcap, std::max(2048, atoi(env)));  // experiment knob
     if (int rc = e->d_pair_q.reserve((size_t)n)) return rc;
     if (int rc = e->d_pair_t.reserve((size_t)n)) return rc;
     if (int rc = e->d_pair_rc.reserve((size_t)n)) return rc;
@@ -321,86 +352,130 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     if (int rc = e->d_results.reserve((size_t)n)) return rc;
     if (int rc = e->d_cigar.reserve((size_t)arena + 64)) return rc;
     if (int rc = e->d_counters.reserve(1 + STAT_N)) return rc;
-    // ---- H2D
-    HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->d_pair_q.p, hq.data(), (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->d_pair_t.p, ht.data(), (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->d_pair_rc.p, hrc.data(), (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->d_cigar_off.p, hoff.data(), (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemsetAsync(e->d_counters.p, 0, (1 + STAT_N) * sizeof(unsigned long long), e->stream));
-    HIP_TRY(hipEventRecord(e->ev1, e->stream));
-    HIP_TRY(hipEventSynchronize(e->ev1));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-    h2d_ms += ms;
-    // ---- launch
-    KParams kp{};
-    for (int v = 0; v < 4; ++v) kp.seq[v] = s.d_seq[v].p;
-    kp.seq_off = s.d_off.p;
-    kp.seq_len = s.d_len.p;
-    kp.seq2[0] = s.d_seq2[0].p;
-    kp.seq2[1] = s.d_seq2[1].p;
-    kp.seq2_off = s.d_off2.p;
-    kp.seq2_ok = s.d_ok2.p;
-    kp.pair_q = e->d_pair_q.p;
-    kp.pair_t = e->d_pair_t.p;
-    kp.pair_rc = e->d_pair_rc.p;
-    kp.npairs = n;
-    kp.pen = dp;
-    kp.ring = ring;
-    kp.wcap = wcap;
-    kp.ring_mem = e->ring_mem.p;
-    kp.ring_slot_stride = ring_stride;
-    kp.lds_meta_bytes = (int)lds_meta;
-    kp.lds_seq_bytes = (int)lds_seq;
-    kp.sb_cap = sb_cap;
-    kp.wb_cap = wb_cap;
-    kp.hist_mem = e->hist_mem.p;
-    kp.hist_slot_stride = hist_stride;
-    kp.hist_meta_offset = hist_rows;
-    kp.ev_mem = e->ev_mem.p;
-    kp.ev_slot_stride = ev_stride;
-    kp.chunk_mem = e->chunk_mem.p;
-    kp.chunk_slot_stride = chunk_stride;
-    kp.chunks_cap = chunks_cap;
-    kp.cigar = e->d_cigar.p;
-    kp.cigar_off = e->d_cigar_off.p;
-    kp.results = e->d_results.p;
-    kp.work_counter = e->d_counters.p;
-    kp.stats = e->d_counters.p + 1;
-    HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    auto launch = [&](auto kern) -> int {
-      HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
-      hipLaunchKernelGGL(kern, dim3(nslots), dim3(WG), dyn_lds, e->stream, kp);
-      return AWV_OK;
-    };
-    int lrc;
-    if (dp.two_piece) lrc = narrow ? launch(biwfa_align_kernel<true, int16_t>) : launch(biwfa_align_kernel<true, int32_t>);
-    else lrc = narrow ? launch(biwfa_align_kernel<false, int16_t>) : launch(biwfa_align_kernel<false, int32_t>);
-    if (lrc != AWV_OK) return lrc;
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e->ev1, e->stream));
-    HIP_TRY(hipEventSynchronize(e->ev1));
-    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-    kernel_ms += ms;
-    ++launches;
-    // ---- D2H
-    hres.resize((size_t)n);
     static_assert(sizeof(awv_result) == sizeof(DevResult), "result layout");
-    HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    HIP_TRY(hipMemcpyAsync(hres.data(), e->d_results.p, (size_t)n * sizeof(awv_result), hipMemcpyDeviceToHost, e->stream));
-    unsigned long long hstat[1 + STAT_N];
-    HIP_TRY(hipMemcpyAsync(hstat, e->d_counters.p, sizeof(hstat), hipMemcpyDeviceToHost, e->stream));
+    hres.assign((size_t)n, awv_result{});
+    // ---- attempts: the whole batch at row capacity `wcap`, then only the pairs that outgrew it
+    std::vector<awv_result> tres;
+    float ms = 0;
+    for (int wc = wcap;;) {
+      const int64_t m = (int64_t)hq.size();
+      const size_t ring_stride = (size_t)2 * NCOMP * ring * wc * esz;
+      const size_t ev_stride = (size_t)wc;
+      const int chunks_cap = wc / 256 + 2;
+      const size_t chunk_stride = (size_t)2 * ring * chunks_cap;
+      int nslots = (int)std::min<int64_t>(nslots_cfg, m);
+      {  // keep the per-workgroup arenas inside the scratch budget (default 160 GiB of the 288 GB HBM)
+        const size_t fit = std::max<size_t>(1, budget / per_slot(wc));
+        if ((size_t)nslots > fit) nslots = (int)fit;
+      }
+      if (int rc = e->ring_mem.reserve(ring_stride * nslots)) return rc;
+      if (int rc = e->hist_mem.reserve(hist_stride * nslots)) return rc;
+      if (int rc = e->ev_mem.reserve(ev_stride * nslots)) return rc;
+      if (int rc = e->chunk_mem.reserve(chunk_stride * nslots)) return rc;
+      // ---- H2D
+      HIP_TRY(hipEventRecord(e->ev0, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->d_pair_q.p, hq.data(), (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->d_pair_t.p, ht.data(), (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->d_pair_rc.p, hrc.data(), (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->d_cigar_off.p, hoff.data(), (size_t)m * 8, hipMemcpyHostToDevice, e->stream));
+      HIP_TRY(hipMemsetAsync(e->d_counters.p, 0, (1 + STAT_N) * sizeof(unsigned long long), e->stream));
+      HIP_TRY(hipEventRecord(e->ev1, e->stream));
+      HIP_TRY(hipEventSynchronize(e->ev1));
+      HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+      h2d_ms += ms;
+      // ---- launch
+      KParams kp{};
+      for (int v = 0; v < 4; ++v) kp.seq[v] = s.d_seq[v].p;
+      kp.seq_off = s.d_off.p;
+      kp.seq_len = s.d_len.p;
+      kp.seq2[0] = s.d_seq2[0].p;
+      kp.seq2[1] = s.d_seq2[1].p;
+      kp.seq2_off = s.d_off2.p;
+      kp.seq2_ok = s.d_ok2.p;
+      kp.pair_q = e->d_pair_q.p;
+      kp.pair_t = e->d_pair_t.p;
+      kp.pair_rc = e->d_pair_rc.p;
+      kp.npairs = m;
+      kp.pen = dp;
+      kp.ring = ring;
+      kp.wcap = wc;
+      kp.ring_mem = e->ring_mem.p;
+      kp.ring_slot_stride = ring_stride;
+      kp.lds_meta_bytes = (int)lds_meta;
+      kp.lds_seq_bytes = (int)lds_seq;
+      kp.sb_cap = sb_cap;
+      kp.wb_cap = wb_cap;
+      kp.hist_mem = e->hist_mem.p;
+      kp.hist_slot_stride = hist_stride;
+      kp.hist_meta_offset = hist_rows;
+      kp.ev_mem = e->ev_mem.p;
+      kp.ev_slot_stride = ev_stride;
+      kp.chunk_mem = e->chunk_mem.p;
+      kp.chunk_slot_stride = chunk_stride;
+      kp.chunks_cap = chunks_cap;
+      kp.cigar = e->d_cigar.p;
+      kp.cigar_off = e->d_cigar_off.p;
+      kp.results = e->d_results.p;
+      kp.work_counter = e->d_counters.p;
+      kp.stats = e->d_counters.p + 1;
+      HIP_TRY(hipEventRecord(e->ev0, e->stream));
+      auto launch = [&](auto kern) -> int {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+        hipLaunchKernelGGL(kern, dim3(nslots), dim3(WG), dyn_lds, e->stream, kp);
+        return AWV_OK;
+      };
+      int lrc;
+      if (dp.two_piece) lrc = narrow ? launch(biwfa_align_kernel<true, int16_t>) : launch(biwfa_align_kernel<true, int32_t>);
+      else lrc = narrow ? launch(biwfa_align_kernel<false, int16_t>) : launch(biwfa_align_kernel<false, int32_t>);
+      if (lrc != AWV_OK) return lrc;
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(e->ev1, e->stream));
+      HIP_TRY(hipEventSynchronize(e->ev1));
+      HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+      kernel_ms += ms;
+      ++launches;
+      // ---- D2H (results + counters)
+      tres.resize((size_t)m);
+      HIP_TRY(hipEventRecord(e->ev0, e->stream));
+      HIP_TRY(hipMemcpyAsync(tres.data(), e->d_results.p, (size_t)m * sizeof(awv_result), hipMemcpyDeviceToHost, e->stream));
+      unsigned long long hstat[1 + STAT_N];
+      HIP_TRY(hipMemcpyAsync(hstat, e->d_counters.p, sizeof(hstat), hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipEventRecord(e->ev1, e->stream));
+      HIP_TRY(hipEventSynchronize(e->ev1));
+      HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+      d2h_ms += ms;
+      for (int i = 0; i < STAT_N; ++i) stat_tot[i] += hstat[1 + i];
+      // ---- scatter; collect the pairs to re-run with wider rows
+      std::vector<int64_t> again;
+      for (int64_t i = 0; i < m; ++i) {
+        const int64_t bi = amap.empty() ? i : amap[(size_t)i];
+        hres[(size_t)bi] = tres[(size_t)i];
+        if (tres[(size_t)i].status == AWV_ST_CAPACITY && wc < wcap_full) again.push_back(i);
+      }
+      if (again.empty()) break;
+      std::vector<int32_t> q2, t2, rc2;
+      std::vector<uint64_t> off2;
+      std::vector<int64_t> map2;
+      for (int64_t i : again) {
+        q2.push_back(hq[(size_t)i]);
+        t2.push_back(ht[(size_t)i]);
+        rc2.push_back(hrc[(size_t)i]);
+        off2.push_back(hoff[(size_t)i]);
+        map2.push_back(amap.empty() ? i : amap[(size_t)i]);
+      }
+      hq.swap(q2); ht.swap(t2); hrc.swap(rc2); hoff.swap(off2); amap.swap(map2);
+      wc = (int)std::min<long long>(wcap_full, 4LL * wc);
+    }
     const bool want_cigar = sink && !(e->cfg.flags & AWV_F_KEEP_ON_DEVICE);
     if (want_cigar) {
       e->h_cigar.resize((size_t)arena + 64);
+      HIP_TRY(hipEventRecord(e->ev0, e->stream));
       HIP_TRY(hipMemcpyAsync(e->h_cigar.data(), e->d_cigar.p, (size_t)arena, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipEventRecord(e->ev1, e->stream));
+      HIP_TRY(hipEventSynchronize(e->ev1));
+      HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+      d2h_ms += ms;
     }
-    HIP_TRY(hipEventRecord(e->ev1, e->stream));
-    HIP_TRY(hipEventSynchronize(e->ev1));
-    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-    d2h_ms += ms;
-    for (int i = 0; i < STAT_N; ++i) stat_tot[i] += hstat[1 + i];
     if (out) std::memcpy(out + first, hres.data(), (size_t)n * sizeof(awv_result));
     if (sink) {
       const int rc = sink(user, first, n, hres.data(), want_cigar ? e->h_cigar.data() : nullptr);
