@@ -605,12 +605,16 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
         }
         const short tl1 = (short)(tlen + 1);
         const s2 tlen1 = {tl1, tl1};
-        auto canon = [&](s2 v) {  // v < 0 ? NULL16 : min(v, tlen + 1)   (what buf_store_vec does per element)
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        const us2 null_u = {(unsigned short)NULL16, (unsigned short)NULL16};
+        // what buf_store_vec does per element, v < 0 ? NULL16 : min(v, tlen + 1), in two packed ops:
+        // every negative value is NULL16 + n (n >= 0), i.e. >= 0xC000 as an unsigned half
+        auto canon = [&](s2 v) {
           const s2 c = __builtin_elementwise_min(v, tlen1);
-          const s2 neg = v >> 15;  // 0xFFFF where negative
-          return (neg & nullv) | (~neg & c);
+          return __builtin_bit_cast(s2, __builtin_elementwise_min(__builtin_bit_cast(us2, c), null_u));
         };
         RawVec<OffT> oI1, oD1, oI2, oD2;
+        const int hbase = plen + k0;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const s2 ins1 = __builtin_elementwise_max(as2(rO1l.w[r]), as2(rI1.w[r])) + one;
@@ -626,16 +630,15 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
             oI2.w[r] = asu(canon(ins2));
             oD2.w[r] = asu(canon(del2));
           }
-          const s2 mm = __builtin_elementwise_max(del, __builtin_elementwise_max(as2(rMx.w[r]) + one, ins));
-          const int ka = k0 + 2 * r;
-          const s2 hmax = {(short)max(min(tlen, plen + ka), -1), (short)max(min(tlen, plen + ka + 1), -1)};
-          const s2 over = (__builtin_elementwise_min(mm, hmax) - mm) >> 15;  // 0xFFFF where mm > hmax
-          const s2 neg = mm >> 15;
-          lane_oob |= asu(over & ~neg) != 0u;  // a non-NULL value of the cell is out of bounds
-          const s2 bad = over | neg;
-          const s2 mv = (bad & nullv) | (~bad & mm);
-          m[2 * r] = (int)mv[0] < 0 ? OFF_NULL : (int)mv[0];
-          m[2 * r + 1] = (int)mv[1] < 0 ? OFF_NULL : (int)mv[1];
+          const s2 mm2 = __builtin_elementwise_max(del, __builtin_elementwise_max(as2(rMx.w[r]) + one, ins));
+          // bounds on sign-extended halves, as the 32-bit path below: in bounds <=> 0 <= mm <= hmax
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int mm = (int)mm2[e];
+            const int hmax = max(min(hbase + 2 * r + e, tlen), -1);
+            lane_oob |= mm > hmax;
+            m[2 * r + e] = (mm > hmax || mm < 0) ? OFF_NULL : mm;
+          }
         }
         if (lane_on) {
           typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
