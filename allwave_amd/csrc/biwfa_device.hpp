@@ -1159,50 +1159,78 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
     if (j >= c0lo && j <= c0hi && j1 >= c1lo && j1 <= c1hi) ok = ck0[j] + ck1[j1] >= L;
     return __ballot(ok);
   };
-  auto scan = [&](int c, int i, int si, uint64_t cmask) {
-    const RowMeta r0 = uni(meta_load(&lds.ring_meta[(d0 * NCOMP + c) * kp.ring + slot0]));
-    const RowMeta r1 = uni(meta_load(&lds.ring_meta[(d1 * NCOMP + c) * kp.ring + (si & rmask)]));
-    if (row_empty(r0) || row_empty(r1)) return;
-    const int a = max(r0.lo, D - r1.hi), b = min(r0.hi, D - r1.lo);
-    if (a > b) return;
-    const int ca = a - kmin0, cbn = b - kmin0;
-    const int chlo = ca >> 8, chhi = cbn >> 8;
-    uint64_t todo;
-    if (chhi >= 64) todo = ~0ull;  // unfiltered: handled by the plain loop below
-    else todo = cmask & ((chhi >= 63 ? ~0ull : ((1ull << (chhi + 1)) - 1)) & ~((1ull << chlo) - 1));
-    if (todo == 0) return;
-    if (tid == 0) lstats[STAT_OVERLAP] += 1;
-    const int so0 = row_off<false, OffT>(kp, d0, c, s0), so1 = row_off<false, OffT>(kp, d1, c, si);
+  // All components of one score pair are scanned together: per candidate chunk the rows of every
+  // wanted component are loaded back to back (one memory round trip), then compared in turn.
+  // Per component the first hit in ascending k wins, as in the sequential search.
+  auto scan_all = [&](int i, int si, uint64_t cmask, unsigned want) {
+    int ca[NCOMP], cbn[NCOMP], so0[NCOMP], so1[NCOMP];
+    unsigned live = 0;
+    int chlo = INT_MAX, chhi = -1;
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      ca[c] = 1; cbn[c] = 0; so0[c] = so1[c] = 0;
+      if (!P2 && (c == C_I2 || c == C_D2)) continue;
+      if (!((want >> c) & 1u)) continue;
+      const RowMeta r0 = uni(meta_load(&lds.ring_meta[(d0 * NCOMP + c) * kp.ring + slot0]));
+      const RowMeta r1 = uni(meta_load(&lds.ring_meta[(d1 * NCOMP + c) * kp.ring + (si & rmask)]));
+      if (row_empty(r0) || row_empty(r1)) continue;
+      const int a = max(r0.lo, D - r1.hi), b = min(r0.hi, D - r1.lo);
+      if (a > b) continue;
+      ca[c] = a - kmin0;
+      cbn[c] = b - kmin0;
+      so0[c] = row_off<false, OffT>(kp, d0, c, s0);
+      so1[c] = row_off<false, OffT>(kp, d1, c, si);
+      live |= 1u << c;
+      chlo = min(chlo, ca[c] >> 8);
+      chhi = max(chhi, cbn[c] >> 8);
+    }
+    if (!live) return;
     int nth = 0;  // waves take the candidate chunks round-robin, each in ascending order
-    for (int ch = chlo; ch <= chhi; ++ch) {
-      if (chhi < 64 && !((todo >> ch) & 1ull)) continue;
+    for (int ch = chlo; ch <= chhi && live; ++ch) {
+      if (ch < 64 && !((cmask >> ch) & 1ull)) continue;  // (chunks >= 64 are not filtered)
+      unsigned here = 0;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c)
+        if (((live >> c) & 1u) && ch >= (ca[c] >> 8) && ch <= (cbn[c] >> 8)) here |= 1u << c;
+      if (!here) continue;
       if ((nth++ % (WG / 64)) != wave) continue;
+      if (tid == 0) lstats[STAT_OVERLAP] += (unsigned long long)__builtin_popcount(here);
       const int cbase = ch << 8;
       const int c0 = cbase + lane * VEC;
-      const RawVec<OffT> q0 = buf_load_raw<OffT>(ring_rs, c0 * ESZ, so0);
-      const RawVec<OffT> q1 = buf_load_raw<OffT>(ring_rs, (Cm - c0 - (VEC - 1)) * ESZ, so1);  // mirrored: v1[VEC-1-j] pairs with v0[j]
-      int32_t v0[VEC], v1[VEC];
-      unpack_raw<OffT>(q0, v0);
-      unpack_raw<OffT>(q1, v1);
-      int first = VEC;
+      RawVec<OffT> q0[NCOMP], q1[NCOMP];
 #pragma unroll
-      for (int j = VEC - 1; j >= 0; --j) {
-        const int col0 = c0 + j;
-        const int k0 = col0 + kmin0, k1 = D - k0;
-        const int32_t h0 = v0[j] < 0 ? OFF_NULL : v0[j], h1 = v1[VEC - 1 - j] < 0 ? OFF_NULL : v1[VEC - 1 - j];
-        bool cond = col0 >= ca && col0 <= cbn && (h0 + h1 >= tlen);
-        if (c != C_M) {  // indel2indel skips out-of-bounds forward coordinates
-          const int kf = fwd ? k0 : k1, hf = fwd ? h0 : h1;
-          cond = cond && !((hf - kf) > plen || hf > tlen);
-        }
-        if (cond) first = j;
+      for (int c = 0; c < NCOMP; ++c) {
+        if (!P2 && (c == C_I2 || c == C_D2)) continue;
+        q0[c] = buf_load_raw<OffT>(ring_rs, c0 * ESZ, so0[c]);
+        q1[c] = buf_load_raw<OffT>(ring_rs, (Cm - c0 - (VEC - 1)) * ESZ, so1[c]);  // mirrored: v1[VEC-1-j] pairs with v0[j]
       }
-      const uint64_t mask = __ballot(first < VEC);
-      if (mask) {
-        const int src = (int)__builtin_ctzll(mask);
-        const int fj = __builtin_amdgcn_readlane(first, src);
-        if (lane == 0) atomicMin(&lds.firstk[i * NCOMP + c], cbase + src * VEC + fj + kmin0);
-        break;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        if (!P2 && (c == C_I2 || c == C_D2)) continue;
+        if (!((here >> c) & 1u)) continue;
+        int32_t v0[VEC], v1[VEC];
+        unpack_raw<OffT>(q0[c], v0);
+        unpack_raw<OffT>(q1[c], v1);
+        int first = VEC;
+#pragma unroll
+        for (int j = VEC - 1; j >= 0; --j) {
+          const int col0 = c0 + j;
+          const int k0 = col0 + kmin0, k1 = D - k0;
+          const int32_t h0 = v0[j] < 0 ? OFF_NULL : v0[j], h1 = v1[VEC - 1 - j] < 0 ? OFF_NULL : v1[VEC - 1 - j];
+          bool cond = col0 >= ca[c] && col0 <= cbn[c] && (h0 + h1 >= tlen);
+          if (c != C_M) {  // indel2indel skips out-of-bounds forward coordinates
+            const int kf = fwd ? k0 : k1, hf = fwd ? h0 : h1;
+            cond = cond && !((hf - kf) > plen || hf > tlen);
+          }
+          if (cond) first = j;
+        }
+        const uint64_t mask = __ballot(first < VEC);
+        if (mask) {
+          const int src = (int)__builtin_ctzll(mask);
+          const int fj = __builtin_amdgcn_readlane(first, src);
+          if (lane == 0) atomicMin(&lds.firstk[i * NCOMP + c], cbase + src * VEC + fj + kmin0);
+          live &= ~(1u << c);
+        }
       }
     }
   };
@@ -1216,9 +1244,7 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
       if (!(w2 || w1 || w0)) continue;
       const uint64_t cmask = chunk_mask(si);
       if (cmask == 0) continue;
-      if (w2) { scan(C_D2, i, si, cmask); scan(C_I2, i, si, cmask); }
-      if (w1) { scan(C_D1, i, si, cmask); scan(C_I1, i, si, cmask); }
-      if (w0) scan(C_M, i, si, cmask);
+      scan_all(i, si, cmask, (w2 ? (1u << C_D2) | (1u << C_I2) : 0u) | (w1 ? (1u << C_D1) | (1u << C_I1) : 0u) | (w0 ? 1u << C_M : 0u));
     }
   }
   __syncthreads();
