@@ -486,20 +486,54 @@ __device__ __forceinline__ void plan_step(const KParams& kp, const Lds<OffT>& ld
   }
 }
 
+// Neighbour-shifted copies of a lane vector, built in registers: lane l's vector holds diagonals
+// k0..k0+3; shift_from_left gives k0-1..k0+2 (the missing element is lane l-1's last one), and
+// shift_from_right gives k0+1..k0+4 (lane l+1's first one).  Full-wave DPP shifts (wave_shr:1 /
+// wave_shl:1) move the halo element; lanes 0 / 63 receive nothing useful and are not productive.
+__device__ __forceinline__ unsigned dpp_from_lower_lane(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned dpp_from_upper_lane(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ RawVec<int16_t> shift_from_left(const RawVec<int16_t>& c) {
+  RawVec<int16_t> o;
+  o.w[0] = __builtin_amdgcn_alignbit(c.w[0], dpp_from_lower_lane(c.w[1]), 16);
+  o.w[1] = __builtin_amdgcn_alignbit(c.w[1], c.w[0], 16);
+  return o;
+}
+__device__ __forceinline__ RawVec<int16_t> shift_from_right(const RawVec<int16_t>& c) {
+  RawVec<int16_t> o;
+  o.w[0] = __builtin_amdgcn_alignbit(c.w[1], c.w[0], 16);
+  o.w[1] = __builtin_amdgcn_alignbit(dpp_from_upper_lane(c.w[0]), c.w[1], 16);
+  return o;
+}
+__device__ __forceinline__ RawVec<int32_t> shift_from_left(const RawVec<int32_t>& c) {
+  RawVec<int32_t> o;
+  o.w[0] = dpp_from_lower_lane(c.w[3]); o.w[1] = c.w[0]; o.w[2] = c.w[1]; o.w[3] = c.w[2];
+  return o;
+}
+__device__ __forceinline__ RawVec<int32_t> shift_from_right(const RawVec<int32_t>& c) {
+  RawVec<int32_t> o;
+  o.w[0] = c.w[1]; o.w[1] = c.w[2]; o.w[2] = c.w[3]; o.w[3] = dpp_from_upper_lane(c.w[0]);
+  return o;
+}
+
 // One compute-next + extend step of one direction (A.3 + A.4).  Every lane owns VEC consecutive
-// diagonals (one 16-byte vector per row); the k-1 / k+1 neighbours come from element-shifted
-// vector loads.  Output rows are written untrimmed; max antidiagonal / oob land in `acc`.
-// Returns the number of cells.
+// diagonals and loads ONE naturally aligned vector per source row; the k-1 / k+1 neighbours are
+// assembled in registers from the adjacent lanes (shift_from_left / shift_from_right), so lanes 0 and
+// 63 of a window only feed their neighbours: a window produces 62 * VEC = 248 columns and windows
+// overlap by one lane vector on each side.  Output rows are written untrimmed; max antidiagonal /
+// oob land in `acc`.  Returns the number of cells.
 template <bool P2, bool BASE, typename OffT>
 __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const Lds<OffT>& lds, const SubCtx& cx, rsrc_t rs,
                                            int dir, int score, const StepPlan& pl, Acc& acc, unsigned& ext_iters) {
+  static_assert(WG == 64, "one wave per pair: a row's windows are walked by a single wave");
   constexpr int VEC = OffTraits<OffT>::VEC;
   static_assert(VEC == 4, "lane vectors are 4 diagonals wide");
   constexpr int WSPAN = 64 * VEC;
-  static_assert(WSPAN == 256, "chunk = 256 columns");
+  static_assert(WSPAN == 256, "window = 256 columns (64 lane vectors), chunk = 256 columns");
+  constexpr int PROD = 62;                // productive lanes 1..62
+  constexpr int WSTRIDE = PROD * VEC;     // 248 new columns per window
   constexpr int ESZ = (int)sizeof(OffT);
   const DevPenalties& pn = kp.pen;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   const int kmin = cx.kmin[dir];
   const int lo = pl.lo, hi = pl.hi;
   if (lo > hi) return 0;  // null step: all rows empty
@@ -525,20 +559,17 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
   const int colLo = lo - kmin, colHi = hi - kmin;
   int lane_maxak = 0;
   bool lane_oob = false;
-  // One wave per pair: the wave's 256-column window starts at the row's first column (rounded to a
-  // lane vector), so a row of width W takes ceil(W / 256) iterations wherever it lies.  Lanes
-  // [0, split) of every iteration fall in absolute chunk cb >> 8, the rest in the next one (the
-  // overlap filter keeps its maxima per absolute chunk).  Several waves per pair keep whole chunks.
-  constexpr bool ROW_ALIGNED = (WG == 64);
-  const int cb_first = ROW_ALIGNED ? (colLo & ~(VEC - 1)) : (colLo & ~(WSPAN - 1)) + WSPAN * wave;
-  const int split = (WSPAN - (cb_first & (WSPAN - 1))) / VEC;  // 1..64, constant over the row
-  int carry_ak = 0, last_cb = cb_first;
-  for (int cb = cb_first; cb <= colHi; cb += WSPAN * (WG / 64)) {
+  // The overlap filter keeps the M row's antidiagonal maxima per absolute 256-column chunk; a window
+  // touches at most two chunks, and a chunk's maximum is carried until the walk leaves the chunk.
+  int* const ck = BASE ? nullptr : lds.chunk_ak + ((size_t)dir * kp.ring + (score & (kp.ring - 1))) * kp.chunks_cap;
+  int cur_chunk = -1, cur_max = 0;
+  const bool productive = lane >= 1 && lane <= PROD;
+  for (int cb = (colLo & ~(VEC - 1)) - VEC; cb + VEC <= colHi; cb += WSTRIDE) {  // lane 1 owns columns cb+4..cb+7
     const int c0 = cb + lane * VEC;
     const int k0 = c0 + kmin;
-    const int voff = (c0 - 1) * ESZ;  // byte offset of diagonal k0-1; shifts are immediates
-    // wave-uniform: does this wave's span (with its +-1 halo) lie inside every present source?
-    const int sl = cb + kmin - 1, sr = cb + kmin + WSPAN;
+    const int voff = c0 * ESZ;  // naturally aligned lane vector
+    // wave-uniform: do the productive columns (with their +-1 halo) lie inside every present source?
+    const int sl = cb + VEC + kmin - 1, sr = cb + (PROD + 1) * VEC + kmin;
     bool interior = true;
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
@@ -546,185 +577,157 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
       interior = interior && pl.src[r].lo <= sl && sr <= pl.src[r].hi;  // (an empty row fails: lo > hi)
     }
     // All row loads are issued back to back with no control flow in between (absent rows read a
-    // valid dummy row), so the wave waits for memory once; unpack / mask afterwards.
+    // valid dummy row), so the wave waits for memory once; mask / shift afterwards.
     const unsigned long long tc0 = PROF_NOW();
-    // lanes whose four diagonals lie wholly outside [lo, hi] neither load nor store (their values
-    // are NULL by construction and nobody reads outside a row's range): edge chunks cost no traffic
-    const bool lane_on = c0 + VEC > colLo && c0 <= colHi;
-    RawVec<OffT> rMx{}, rO1l{}, rO1r{}, rI1{}, rD1{}, rO2l{}, rO2r{}, rI2{}, rD2{};
-    if (lane_on) {
-      rMx = buf_load_raw<OffT>(rs, voff + ESZ, sMx);
-      rO1l = buf_load_raw<OffT>(rs, voff, sO1);
-      rO1r = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sO1);
-      rI1 = buf_load_raw<OffT>(rs, voff, sI1);
-      rD1 = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sD1);
+    // lanes whose four diagonals lie wholly outside [lo, hi] neither compute nor store (their values
+    // are NULL by construction and nobody reads outside a row's range); their neighbours still load
+    const bool lane_on = productive && c0 + VEC > colLo && c0 <= colHi;
+    const bool load_on = c0 + 2 * VEC > colLo && c0 - VEC <= colHi;
+    RawVec<OffT> cMx{}, cO1{}, cI1{}, cD1{}, cO2{}, cI2{}, cD2{};
+    if (load_on) {
+      cMx = buf_load_raw<OffT>(rs, voff, sMx);
+      cO1 = buf_load_raw<OffT>(rs, voff, sO1);
+      cI1 = buf_load_raw<OffT>(rs, voff, sI1);
+      cD1 = buf_load_raw<OffT>(rs, voff, sD1);
       if (P2) {
-        rO2l = buf_load_raw<OffT>(rs, voff, sO2);
-        rO2r = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sO2);
-        rI2 = buf_load_raw<OffT>(rs, voff, sI2);
-        rD2 = buf_load_raw<OffT>(rs, voff + 2 * ESZ, sD2);
+        cO2 = buf_load_raw<OffT>(rs, voff, sO2);
+        cI2 = buf_load_raw<OffT>(rs, voff, sI2);
+        cD2 = buf_load_raw<OffT>(rs, voff, sD2);
       }
     }
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_LOAD, tc0);
     const unsigned long long tc1 = PROF_NOW();
     int32_t m[VEC];
-    bool packed_done = false;
-#ifndef AWV_NO_PACKED_DP
-    if constexpr (sizeof(OffT) == 2) {
-      {
-        // ---- 16-bit rows: the DP runs on packed pairs (v_pk_max_i16 / v_pk_add_u16 / v_pk_min_i16),
-        // two diagonals per instruction.  All values fit 16 bits (offsets <= tlen + 1, NULL16 = -16384,
-        // at most +1 per step before the store re-canonicalises), so the ordering and results are
-        // those of the 32-bit arithmetic used for 32-bit rows below.
-        typedef short s2 __attribute__((ext_vector_type(2)));
-        auto as2 = [](unsigned w) { return __builtin_bit_cast(s2, w); };
-        auto asu = [](s2 v) { return __builtin_bit_cast(unsigned, v); };
-        const s2 one = {1, 1}, nullv = {(short)NULL16, (short)NULL16};
-        if (!interior) {  // edge waves (or a source row absent/narrower): NULL out what lies outside each row's range
-          auto mask = [&](const RowMeta& mm, int shift, RawVec<OffT>& v) {
+    if (!interior) {  // edge windows (or a source row absent/narrower): NULL out what lies outside each row's own range
+      auto mask = [&](const RowMeta& mm, RawVec<OffT>& v) {
+        if constexpr (sizeof(OffT) == 2) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-              const int ka = k0 + shift + 2 * r;
-              const unsigned keep = ((ka >= mm.lo && ka <= mm.hi) ? 0x0000FFFFu : 0u) |
-                                    ((ka + 1 >= mm.lo && ka + 1 <= mm.hi) ? 0xFFFF0000u : 0u);
-              v.w[r] = (v.w[r] & keep) | (asu(nullv) & ~keep);
-            }
-          };
-          mask(pl.src[0], 0, rMx);
-          mask(pl.src[1], -1, rO1l);
-          mask(pl.src[1], +1, rO1r);
-          mask(pl.src[2], -1, rI1);
-          mask(pl.src[3], +1, rD1);
-          if (P2) {
-            mask(pl.src[4], -1, rO2l);
-            mask(pl.src[4], +1, rO2r);
-            mask(pl.src[5], -1, rI2);
-            mask(pl.src[6], +1, rD2);
+          for (int r = 0; r < 2; ++r) {
+            const int ka = k0 + 2 * r;
+            const unsigned keep = ((ka >= mm.lo && ka <= mm.hi) ? 0x0000FFFFu : 0u) |
+                                  ((ka + 1 >= mm.lo && ka + 1 <= mm.hi) ? 0xFFFF0000u : 0u);
+            const unsigned nullw = ((unsigned)(unsigned short)NULL16) * 0x00010001u;
+            v.w[r] = (v.w[r] & keep) | (nullw & ~keep);
           }
-        }
-        const short tl1 = (short)(tlen + 1);
-        const s2 tlen1 = {tl1, tl1};
-        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-        const us2 null_u = {(unsigned short)NULL16, (unsigned short)NULL16};
-        // what buf_store_vec does per element, v < 0 ? NULL16 : min(v, tlen + 1), in two packed ops:
-        // every negative value is NULL16 + n (n >= 0), i.e. >= 0xC000 as an unsigned half
-        auto canon = [&](s2 v) {
-          const s2 c = __builtin_elementwise_min(v, tlen1);
-          return __builtin_bit_cast(s2, __builtin_elementwise_min(__builtin_bit_cast(us2, c), null_u));
-        };
-        RawVec<OffT> oI1, oD1, oI2, oD2;
-        const int hbase = plen + k0;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const s2 ins1 = __builtin_elementwise_max(as2(rO1l.w[r]), as2(rI1.w[r])) + one;
-          const s2 del1 = __builtin_elementwise_max(as2(rO1r.w[r]), as2(rD1.w[r]));
-          s2 ins = ins1, del = del1;
-          oI1.w[r] = asu(canon(ins1));
-          oD1.w[r] = asu(canon(del1));
-          if (P2) {
-            const s2 ins2 = __builtin_elementwise_max(as2(rO2l.w[r]), as2(rI2.w[r])) + one;
-            const s2 del2 = __builtin_elementwise_max(as2(rO2r.w[r]), as2(rD2.w[r]));
-            ins = __builtin_elementwise_max(ins, ins2);
-            del = __builtin_elementwise_max(del, del2);
-            oI2.w[r] = asu(canon(ins2));
-            oD2.w[r] = asu(canon(del2));
-          }
-          const s2 mm2 = __builtin_elementwise_max(del, __builtin_elementwise_max(as2(rMx.w[r]) + one, ins));
-          // bounds on sign-extended halves, as the 32-bit path below: in bounds <=> 0 <= mm <= hmax
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int mm = (int)mm2[e];
-            const int hmax = max(min(hbase + 2 * r + e, tlen), -1);
-            lane_oob |= mm > hmax;
-            m[2 * r + e] = (mm > hmax || mm < 0) ? OFF_NULL : mm;
-          }
+          for (int j = 0; j < VEC; ++j) v.w[j] = (k0 + j >= mm.lo && k0 + j <= mm.hi) ? v.w[j] : (unsigned)OFF_NULL;
         }
-        if (lane_on) {
-          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-          auto st = [&](int soff, const RawVec<OffT>& v) {
-            u32x2 raw;
-            raw[0] = v.w[0];
-            raw[1] = v.w[1];
-            __builtin_amdgcn_raw_buffer_store_b64(raw, rs, voff + ESZ, soff, 0);
-          };
-          st(tI1, oI1);
-          st(tD1, oD1);
-          if (P2) { st(tI2, oI2); st(tD2, oD2); }
-        }
-        packed_done = true;
+      };
+      mask(pl.src[0], cMx);
+      mask(pl.src[1], cO1);
+      mask(pl.src[2], cI1);
+      mask(pl.src[3], cD1);
+      if (P2) {
+        mask(pl.src[4], cO2);
+        mask(pl.src[5], cI2);
+        mask(pl.src[6], cD2);
       }
     }
-#endif
-    if (!packed_done) {
-      int32_t vMx[VEC], vO1l[VEC], vO1r[VEC], vI1[VEC], vD1[VEC], vO2l[VEC], vO2r[VEC], vI2[VEC], vD2[VEC];
-      unpack_raw<OffT>(rMx, vMx);
-      unpack_raw<OffT>(rO1l, vO1l);
-      unpack_raw<OffT>(rO1r, vO1r);
-      unpack_raw<OffT>(rI1, vI1);
-      unpack_raw<OffT>(rD1, vD1);
-      if (P2) {
-        unpack_raw<OffT>(rO2l, vO2l);
-        unpack_raw<OffT>(rO2r, vO2r);
-        unpack_raw<OffT>(rI2, vI2);
-        unpack_raw<OffT>(rD2, vD2);
-      }
-      if (!interior) {  // edge waves (or a source row absent/narrower): mask by each row's own range
-        auto mask = [&](const RowMeta& mm, int shift, int32_t (&v)[VEC]) {
+    const RawVec<OffT> rO1l = shift_from_left(cO1), rO1r = shift_from_right(cO1);
+    const RawVec<OffT> rI1 = shift_from_left(cI1), rD1 = shift_from_right(cD1);
+    RawVec<OffT> rO2l{}, rO2r{}, rI2{}, rD2{};
+    if (P2) {
+      rO2l = shift_from_left(cO2);
+      rO2r = shift_from_right(cO2);
+      rI2 = shift_from_left(cI2);
+      rD2 = shift_from_right(cD2);
+    }
+    const int hbase = plen + k0;
+    if constexpr (sizeof(OffT) == 2) {
+      // ---- 16-bit rows: the DP runs on packed pairs (v_pk_max_i16 / v_pk_add_u16 / v_pk_min_i16),
+      // two diagonals per instruction.  All values fit 16 bits (offsets <= tlen + 1, NULL16 = -16384,
+      // at most +1 per step before the store re-canonicalises), so the ordering and results are
+      // those of the 32-bit arithmetic used for 32-bit rows below.
+      typedef short s2 __attribute__((ext_vector_type(2)));
+      typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+      auto as2 = [](unsigned w) { return __builtin_bit_cast(s2, w); };
+      auto asu = [](s2 v) { return __builtin_bit_cast(unsigned, v); };
+      const s2 one = {1, 1};
+      const short tl1 = (short)(tlen + 1);
+      const s2 tlen1 = {tl1, tl1};
+      const us2 null_u = {(unsigned short)NULL16, (unsigned short)NULL16};
+      // what buf_store_vec does per element, v < 0 ? NULL16 : min(v, tlen + 1), in two packed ops:
+      // every negative value is NULL16 + n (n >= 0), i.e. >= 0xC000 as an unsigned half
+      auto canon = [&](s2 v) {
+        const s2 c = __builtin_elementwise_min(v, tlen1);
+        return __builtin_bit_cast(s2, __builtin_elementwise_min(__builtin_bit_cast(us2, c), null_u));
+      };
+      RawVec<OffT> oI1, oD1, oI2, oD2;
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) {
-            const int kk = k0 + shift + j;
-            v[j] = (kk >= mm.lo && kk <= mm.hi) ? v[j] : OFF_NULL;
-          }
-        };
-        mask(pl.src[0], 0, vMx);
-        mask(pl.src[1], -1, vO1l);
-        mask(pl.src[1], +1, vO1r);
-        mask(pl.src[2], -1, vI1);
-        mask(pl.src[3], +1, vD1);
+      for (int r = 0; r < 2; ++r) {
+        const s2 ins1 = __builtin_elementwise_max(as2(rO1l.w[r]), as2(rI1.w[r])) + one;
+        const s2 del1 = __builtin_elementwise_max(as2(rO1r.w[r]), as2(rD1.w[r]));
+        s2 ins = ins1, del = del1;
+        oI1.w[r] = asu(canon(ins1));
+        oD1.w[r] = asu(canon(del1));
         if (P2) {
-          mask(pl.src[4], -1, vO2l);
-          mask(pl.src[4], +1, vO2r);
-          mask(pl.src[5], -1, vI2);
-          mask(pl.src[6], +1, vD2);
+          const s2 ins2 = __builtin_elementwise_max(as2(rO2l.w[r]), as2(rI2.w[r])) + one;
+          const s2 del2 = __builtin_elementwise_max(as2(rO2r.w[r]), as2(rD2.w[r]));
+          ins = __builtin_elementwise_max(ins, ins2);
+          del = __builtin_elementwise_max(del, del2);
+          oI2.w[r] = asu(canon(ins2));
+          oD2.w[r] = asu(canon(del2));
+        }
+        const s2 mm2 = __builtin_elementwise_max(del, __builtin_elementwise_max(as2(cMx.w[r]) + one, ins));
+        // bounds on sign-extended halves, as the 32-bit path below: in bounds <=> 0 <= mm <= hmax
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int mm = (int)mm2[e];
+          const int hmax = max(min(hbase + 2 * r + e, tlen), -1);
+          lane_oob |= lane_on && mm > hmax;
+          m[2 * r + e] = (mm > hmax || mm < 0 || !lane_on) ? OFF_NULL : mm;
         }
       }
+      if (lane_on) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        auto st = [&](int soff, const RawVec<OffT>& v) {
+          u32x2 w2;
+          w2[0] = v.w[0];
+          w2[1] = v.w[1];
+          __builtin_amdgcn_raw_buffer_store_b64(w2, rs, voff, soff, 0);
+        };
+        st(tI1, oI1);
+        st(tD1, oD1);
+        if (P2) { st(tI2, oI2); st(tD2, oD2); }
+      }
+    } else {
       int32_t ins1[VEC], del1[VEC], ins2[VEC], del2[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const int k = k0 + j;
-        ins1[j] = max(vO1l[j], vI1[j]) + 1;
-        del1[j] = max(vO1r[j], vD1[j]);
+        ins1[j] = max((int32_t)rO1l.w[j], (int32_t)rI1.w[j]) + 1;
+        del1[j] = max((int32_t)rO1r.w[j], (int32_t)rD1.w[j]);
         int32_t ins = ins1[j], del = del1[j];
         if (P2) {
-          ins2[j] = max(vO2l[j], vI2[j]) + 1;
-          del2[j] = max(vO2r[j], vD2[j]);
+          ins2[j] = max((int32_t)rO2l.w[j], (int32_t)rI2.w[j]) + 1;
+          del2[j] = max((int32_t)rO2r.w[j], (int32_t)rD2.w[j]);
           ins = max(ins, ins2[j]);
           del = max(del, del2[j]);
         } else {
           ins2[j] = del2[j] = OFF_NULL;
         }
-        const int32_t mm = max(del, max(vMx[j] + 1, ins));
+        const int32_t mm = max(del, max((int32_t)cMx.w[j] + 1, ins));
         // in-bounds <=> 0 <= value <= hmax.  mm is the max of the cell's five values, so "some
         // non-NULL value of this cell is out of bounds" <=> mm > hmax (any negative is a NULL(+n)).
-        const int hmax = max(min(tlen, plen + k), -1);
-        lane_oob |= mm > hmax;
-        m[j] = (mm > hmax || mm < 0) ? OFF_NULL : mm;
+        const int hmax = max(min(hbase + j, tlen), -1);
+        lane_oob |= lane_on && mm > hmax;
+        m[j] = (mm > hmax || mm < 0 || !lane_on) ? OFF_NULL : mm;
       }
       if (lane_on) {
-        buf_store_vec<OffT>(rs, voff + ESZ, tI1, ins1, tlen);
-        buf_store_vec<OffT>(rs, voff + ESZ, tD1, del1, tlen);
+        buf_store_vec<OffT>(rs, voff, tI1, ins1, tlen);
+        buf_store_vec<OffT>(rs, voff, tD1, del1, tlen);
         if (P2) {
-          buf_store_vec<OffT>(rs, voff + ESZ, tI2, ins2, tlen);
-          buf_store_vec<OffT>(rs, voff + ESZ, tD2, del2, tlen);
+          buf_store_vec<OffT>(rs, voff, tI2, ins2, tlen);
+          buf_store_vec<OffT>(rs, voff, tD2, del2, tlen);
         }
       }
     }
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_ALU, tc1);
     const unsigned long long tc2 = PROF_NOW();
-    // extend (A.4): the first 8-byte probe of all four cells is issued together (invalid cells
-    // probe offset 0, always readable), then the rare long runs continue in a loop
+    // extend (A.4): the first probe of all four cells is issued together (invalid cells probe offset
+    // 0, always readable), then the rare long runs continue in a loop
     int rr[VEC], vv[VEC], hh[VEC];
     uint64_t xx[VEC];
     const bool packed = cx.seq_mode != 0;
@@ -781,30 +784,34 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     for (int j = 0; j < VEC; ++j)
       if (m[j] >= 0) it_maxak = max(it_maxak, 2 * m[j] - (k0 + j));
     if (!BASE) {  // chunk maxima for the overlap filter
-      int* ck = lds.chunk_ak + ((size_t)dir * kp.ring + (score & (kp.ring - 1))) * kp.chunks_cap;
-      if (split == 64) {  // this wave-iteration is exactly one absolute chunk
-        const int cmax = wave_max_i32(it_maxak);
-        if (lane == 0) ck[cb >> 8] = cmax;
-        lane_maxak = max(lane_maxak, cmax);
-      } else {
-        const int lowmax = wave_max_i32(lane < split ? it_maxak : 0);
-        const int upmax = wave_max_i32(lane < split ? 0 : it_maxak);
-        if (lane == 0) ck[cb >> 8] = max(carry_ak, lowmax);
-        carry_ak = upmax;
-        last_cb = cb;
-        lane_maxak = max(lane_maxak, max(lowmax, upmax));
+      const int first_col = cb + VEC;                                // column of lane 1
+      const int chunk_lo = first_col >> 8;
+      const int nlow = (((chunk_lo + 1) << 8) - first_col) / VEC;    // productive lanes 1..nlow lie in chunk_lo
+      if (chunk_lo != cur_chunk) {
+        if (cur_chunk >= 0 && lane == 0) ck[cur_chunk] = cur_max;
+        cur_chunk = chunk_lo;
+        cur_max = 0;
       }
+      if (nlow >= PROD) {
+        cur_max = max(cur_max, wave_max_i32(it_maxak));
+      } else {
+        cur_max = max(cur_max, wave_max_i32(lane <= nlow ? it_maxak : 0));
+        lane_maxak = max(lane_maxak, cur_max);
+        if (lane == 0) ck[cur_chunk] = cur_max;
+        cur_chunk = chunk_lo + 1;
+        cur_max = wave_max_i32(lane <= nlow ? 0 : it_maxak);
+      }
+      lane_maxak = max(lane_maxak, cur_max);  // (row maximum = max over the chunk maxima seen)
     } else {
       lane_maxak = max(lane_maxak, it_maxak);
     }
-    if (lane_on) buf_store_vec<OffT>(rs, voff + ESZ, tM, m, tlen);
+    if (lane_on) buf_store_vec<OffT>(rs, voff, tM, m, tlen);
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_STORE, tc3);
   }
   const unsigned long long tc4 = PROF_NOW();
-  if (!BASE && split != 64 && lane == 0)  // upper part of the last window
-    lds.chunk_ak[((size_t)dir * kp.ring + (score & (kp.ring - 1))) * kp.chunks_cap + (last_cb >> 8) + 1] = carry_ak;
-  const int wmax = BASE ? wave_max_i32(lane_maxak) : lane_maxak;  // (already wave-uniform per chunk otherwise)
+  if (!BASE && cur_chunk >= 0 && lane == 0) ck[cur_chunk] = cur_max;  // the last chunk of the walk
+  const int wmax = BASE ? wave_max_i32(lane_maxak) : lane_maxak;  // (already wave-uniform per window otherwise)
   const bool woob = __any(lane_oob);
   if (lane == 0) {
     atomicMax(&acc.maxak, wmax);
