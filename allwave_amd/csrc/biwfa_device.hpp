@@ -431,6 +431,7 @@ __device__ __forceinline__ void acc_reset(Acc& a) {
 
 struct StepPlan {  // uniform description of one compute-next call
   RowMeta src[7];  // Mx, O1, I1e, D1e, O2, I2e, D2e
+  RowMeta hull[7]; // hull of the step that wrote each source row (= the M row's metadata at that score)
   int lo, hi;      // hull of the cells to compute (= predicted hull of the M row)
 };
 
@@ -452,6 +453,17 @@ __device__ __forceinline__ void plan_step(const KParams& kp, const Lds<OffT>& ld
     pl.src[5] = get_meta<OffT>(kp, lds, dir, C_I2, score - pn.e2);
     pl.src[6] = get_meta<OffT>(kp, lds, dir, C_D2, score - pn.e2);
   }
+  // Every step stores whole lane vectors over its hull for all components (cells outside a
+  // component's own range hold NULL), so while no row has been trimmed a source row can be masked
+  // by whole lane vectors against the hull of the step that wrote it.
+  pl.hull[0] = pl.src[0];
+  pl.hull[1] = pl.src[1];
+  pl.hull[2] = pl.hull[3] = get_meta<OffT>(kp, lds, dir, C_M, score - pn.e1);
+  pl.hull[4] = pl.src[4];
+  pl.hull[5] = pl.hull[6] = P2 ? get_meta<OffT>(kp, lds, dir, C_M, score - pn.e2) : ROW_EMPTY;
+  // (the score-0 row of a sub-problem that begins in an indel component has that cell and no M cell)
+  if (score - pn.e1 == 0) { pl.hull[2] = pl.src[2]; pl.hull[3] = pl.src[3]; }
+  if (P2 && score - pn.e2 == 0) { pl.hull[5] = pl.src[5]; pl.hull[6] = pl.src[6]; }
   // Predicted hulls (exact unless some value goes out of bounds, which the step detects and then
   // repairs in trim_pass): a cell of I (D) is non-NULL iff its left (right) source cell is, M iff
   // any source is (A.3).  They are written to the row metadata right away -- the slot of the new
@@ -523,7 +535,7 @@ __device__ __forceinline__ RawVec<int32_t> shift_from_right(const RawVec<int32_t
 // oob land in `acc`.  Returns the number of cells.
 template <bool P2, bool BASE, typename OffT>
 __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const Lds<OffT>& lds, const SubCtx& cx, rsrc_t rs,
-                                           int dir, int score, const StepPlan& pl, Acc& acc, unsigned& ext_iters) {
+                                           int dir, int score, const StepPlan& pl, bool dirty, Acc& acc, unsigned& ext_iters) {
   static_assert(WG == 64, "one wave per pair: a row's windows are walked by a single wave");
   constexpr int VEC = OffTraits<OffT>::VEC;
   static_assert(VEC == 4, "lane vectors are 4 diagonals wide");
@@ -564,18 +576,27 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
   int* const ck = BASE ? nullptr : lds.chunk_ak + ((size_t)dir * kp.ring + (score & (kp.ring - 1))) * kp.chunks_cap;
   int cur_chunk = -1, cur_max = 0;
   const bool productive = lane >= 1 && lane <= PROD;
+  // Windows that need no masking at all, as a range of window origins [int_lo, int_hi], found once
+  // per row.  With trimmed rows around (`dirty`): the productive columns and their +-1 halo lie
+  // inside every source's own range; otherwise: all 64 lane vectors lie inside the (lane-aligned)
+  // hull of every source's step.
+  int int_lo = INT_MIN, int_hi = INT_MAX;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    if (!P2 && r >= 4) break;
+    if (dirty) {
+      int_lo = max(int_lo, pl.src[r].lo - kmin + 1 - VEC);          // src.lo <= cb + VEC + kmin - 1
+      int_hi = min(int_hi, pl.src[r].hi - kmin - (PROD + 1) * VEC);  // cb + (PROD + 1) * VEC + kmin <= src.hi
+    } else {
+      int_lo = max(int_lo, (pl.hull[r].lo - kmin) & ~(VEC - 1));
+      int_hi = min(int_hi, ((pl.hull[r].hi - kmin) | (VEC - 1)) - 63 * VEC);
+    }
+  }
   for (int cb = (colLo & ~(VEC - 1)) - VEC; cb + VEC <= colHi; cb += WSTRIDE) {  // lane 1 owns columns cb+4..cb+7
     const int c0 = cb + lane * VEC;
     const int k0 = c0 + kmin;
     const int voff = c0 * ESZ;  // naturally aligned lane vector
-    // wave-uniform: do the productive columns (with their +-1 halo) lie inside every present source?
-    const int sl = cb + VEC + kmin - 1, sr = cb + (PROD + 1) * VEC + kmin;
-    bool interior = true;
-#pragma unroll
-    for (int r = 0; r < 7; ++r) {
-      if (!P2 && r >= 4) break;
-      interior = interior && pl.src[r].lo <= sl && sr <= pl.src[r].hi;  // (an empty row fails: lo > hi)
-    }
+    const bool interior = cb >= int_lo && cb <= int_hi;  // wave-uniform
     // All row loads are issued back to back with no control flow in between (absent rows read a
     // valid dummy row), so the wave waits for memory once; mask / shift afterwards.
     const unsigned long long tc0 = PROF_NOW();
@@ -599,7 +620,23 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     PROF_ADD_L(STAT_T_CR_LOAD, tc0);
     const unsigned long long tc1 = PROF_NOW();
     int32_t m[VEC];
-    if (!interior) {  // edge windows (or a source row absent/narrower): NULL out what lies outside each row's own range
+    if (!interior && !dirty) {  // edge windows: lane vectors outside the hull of a source's step hold nothing (or stale data)
+      auto lmask = [&](const RowMeta& h, RawVec<OffT>& v) {
+        const bool keep = c0 >= ((h.lo - kmin) & ~(VEC - 1)) && c0 <= ((h.hi - kmin) | (VEC - 1));  // (empty: never)
+        const unsigned nullw = sizeof(OffT) == 2 ? ((unsigned)(unsigned short)NULL16) * 0x00010001u : (unsigned)OFF_NULL;
+#pragma unroll
+        for (int r = 0; r < (int)(sizeof(v.w) / sizeof(v.w[0])); ++r) v.w[r] = keep ? v.w[r] : nullw;
+      };
+      lmask(pl.hull[0], cMx);
+      lmask(pl.hull[1], cO1);
+      lmask(pl.hull[2], cI1);
+      lmask(pl.hull[3], cD1);
+      if (P2) {
+        lmask(pl.hull[4], cO2);
+        lmask(pl.hull[5], cI2);
+        lmask(pl.hull[6], cD2);
+      }
+    } else if (!interior) {  // some row was trimmed: NULL out, element by element, what lies outside each row's own range
       auto mask = [&](const RowMeta& mm, RawVec<OffT>& v) {
         if constexpr (sizeof(OffT) == 2) {
 #pragma unroll
@@ -943,7 +980,8 @@ __device__ int base_align(const KParams& kp, Shared& sh, const Lds<OffT>& lds, S
     unsigned it = 0;
     int v0 = 0;
     if (cb == C_M) v0 = extend_lcp(cx.P[0], cx.T[0], 0, 0, plen, tlen, it);
-    hist[(size_t)cb * kp.wb_cap + (0 - kmin)] = (OffT)v0;
+    for (int j = 0; j < 4; ++j) hist[(size_t)cb * kp.wb_cap + (((0 - kmin) & ~3) + j)] = (OffT)(sizeof(OffT) == 2 ? NULL16 : OFF_NULL);
+    hist[(size_t)cb * kp.wb_cap + (0 - kmin)] = (OffT)v0;  // the score-0 row: one cell in a whole lane vector
     acc_reset(sh.acc[0][0]);
     acc_reset(sh.acc[1][0]);
     acc_reset(sh.acc[2][0]);
@@ -954,6 +992,7 @@ __device__ int base_align(const KParams& kp, Shared& sh, const Lds<OffT>& lds, S
   unsigned ext_iters = 0;
   unsigned long long cells = 0;
   int pass = 0;
+  bool dirty = false;  // some row of this sub-problem was trimmed: later steps mask element by element
   const unsigned long long tb0 = PROF_NOW();
   for (;;) {
     // termination (wavefront_termination_end2end): end component reaches (plen, tlen)
@@ -967,10 +1006,11 @@ __device__ int base_align(const KParams& kp, Shared& sh, const Lds<OffT>& lds, S
     Acc& acc = sh.acc[pass % 3][0];
     StepPlan pl;
     plan_step<P2, true, OffT>(kp, lds, 0, score, pl);
-    cells += compute_row<P2, true, OffT>(kp, sh, lds, cx, hist_rs, 0, score, pl, acc, ext_iters);
+    cells += compute_row<P2, true, OffT>(kp, sh, lds, cx, hist_rs, 0, score, pl, dirty, acc, ext_iters);
     __syncthreads();
     if (uni(sh.error)) return uni(sh.error);
     const bool trim = uni(acc.oob) != 0;
+    dirty = dirty || trim;
     if (trim) {
       trim_pass<P2, true, OffT>(kp, cx, hist_mem, 0, score, pl.lo, pl.hi, acc);
       __syncthreads();
@@ -1319,7 +1359,12 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
     unsigned it = 0;
     int v0 = 0;
     if (begin == C_M) v0 = extend_lcp(dir ? cx.P[1] : cx.P[0], dir ? cx.T[1] : cx.T[0], 0, 0, plen, tlen, it);
-    row_ptr<false, OffT>(kp, ring_mem, dir, begin, 0)[0 - (dir ? cx.kmin[1] : cx.kmin[0])] = (OffT)v0;
+    {  // the score-0 row: one cell, stored as a whole lane vector like every other row
+      const int col = 0 - (dir ? cx.kmin[1] : cx.kmin[0]);
+      OffT* row = row_ptr<false, OffT>(kp, ring_mem, dir, begin, 0);
+      for (int j = 0; j < 4; ++j) row[(col & ~3) + j] = (OffT)(sizeof(OffT) == 2 ? NULL16 : OFF_NULL);
+      row[col] = (OffT)v0;
+    }
     sh.ext0[dir] = v0;
     lds.chunk_ak[((size_t)dir * kp.ring + 0) * kp.chunks_cap + ((0 - (dir ? cx.kmin[1] : cx.kmin[0])) >> 8)] = (begin == C_M) ? 2 * v0 : 0;
     lds.bi_A[(dir) * kp.ring + (0)] = (begin == C_M) ? 2 * v0 : 0;
@@ -1343,6 +1388,7 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
   int rc = BP_OK;
   const int gap_opening = P2 ? max(pn.o1, pn.o2) : pn.o1;
   bool last_fwd = false;
+  bool dirty[2] = {false, false};  // per direction: some row was trimmed, later steps mask element by element
   int phase = 1;
   // One loop for both phases (A.6).  Each iteration first makes sure the next forward and the next
   // reverse wavefront exist (one fused pass, one barrier), then runs WFA2's bookkeeping for it.
@@ -1359,7 +1405,7 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
         if (need[dir]) {
           StepPlan pl;
           plan_step<P2, false, OffT>(kp, lds, dir, sc[dir] + 1, pl);
-          cells += compute_row<P2, false, OffT>(kp, sh, lds, cx, ring_rs, dir, sc[dir] + 1, pl, a[dir], ext_iters);
+          cells += compute_row<P2, false, OffT>(kp, sh, lds, cx, ring_rs, dir, sc[dir] + 1, pl, dirty[dir], a[dir], ext_iters);
           plo[dir] = pl.lo;
           phi[dir] = pl.hi;
         }
@@ -1373,6 +1419,8 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
         const unsigned long long tp2 = PROF_NOW();
         if (uni(sh.error)) { rc = uni(sh.error); break; }
         const bool trim0 = need[0] && uni(a[0].oob) != 0, trim1 = need[1] && uni(a[1].oob) != 0;
+        dirty[0] = dirty[0] || trim0;
+        dirty[1] = dirty[1] || trim1;
         if (trim0 || trim1) {
           if (trim0) trim_pass<P2, false, OffT>(kp, cx, ring_mem, 0, sc[0] + 1, plo[0], phi[0], a[0]);
           if (trim1) trim_pass<P2, false, OffT>(kp, cx, ring_mem, 1, sc[1] + 1, plo[1], phi[1], a[1]);
