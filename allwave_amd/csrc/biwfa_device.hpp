@@ -263,14 +263,15 @@ template <typename OffT> struct RawVec;
 template <> struct RawVec<int16_t> { unsigned int w[2]; };
 template <> struct RawVec<int32_t> { unsigned int w[4]; };
 
-template <typename OffT>
+// AUX = cache policy bits of the buffer instruction (0 default, 2 = nt: a line read for the last time)
+template <typename OffT, int AUX = 0>
 __device__ __forceinline__ RawVec<OffT> buf_load_raw(rsrc_t r, int voff, int soff) {
   RawVec<OffT> o;
   if constexpr (sizeof(OffT) == 2) {
-    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
     o.w[0] = raw[0]; o.w[1] = raw[1];
   } else {
-    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
     o.w[0] = raw[0]; o.w[1] = raw[1]; o.w[2] = raw[2]; o.w[3] = raw[3];
   }
   return o;
@@ -608,12 +609,14 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     if (load_on) {
       cMx = buf_load_raw<OffT>(rs, voff, sMx);
       cO1 = buf_load_raw<OffT>(rs, voff, sO1);
-      cI1 = buf_load_raw<OffT>(rs, voff, sI1);
-      cD1 = buf_load_raw<OffT>(rs, voff, sD1);
+      // an I/D row is read by exactly one later step (score + e): non-temporal, so that the dead
+      // lines leave L2 / Infinity Cache first (the M rows are read three times, up to `scope` steps later)
+      cI1 = buf_load_raw<OffT, 2>(rs, voff, sI1);
+      cD1 = buf_load_raw<OffT, 2>(rs, voff, sD1);
       if (P2) {
         cO2 = buf_load_raw<OffT>(rs, voff, sO2);
-        cI2 = buf_load_raw<OffT>(rs, voff, sI2);
-        cD2 = buf_load_raw<OffT>(rs, voff, sD2);
+        cI2 = buf_load_raw<OffT, 2>(rs, voff, sI2);
+        cD2 = buf_load_raw<OffT, 2>(rs, voff, sD2);
       }
     }
     PROF_DRAIN();
