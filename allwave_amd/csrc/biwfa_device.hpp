@@ -38,6 +38,13 @@ enum { C_M = 0, C_I1 = 1, C_I2 = 2, C_D1 = 3, C_D2 = 4 };
 constexpr int FALLBACK_MIN_SCORE = 250;
 constexpr int FALLBACK_MIN_LENGTH = 100;
 constexpr int STACK_CAP = 48;
+// Occupancy target: waves per SIMD (the register budget the kernel is compiled for) and the static
+// LDS the kernel declares; the engine sizes the dynamic LDS so that WAVES_PER_SIMD * 4 waves fit a CU.
+#ifndef AWV_WAVES_PER_SIMD
+#define AWV_WAVES_PER_SIMD 4
+#endif
+constexpr int WAVES_PER_SIMD = AWV_WAVES_PER_SIMD;
+constexpr int STATIC_LDS_RESERVE = 640;
 constexpr int COL_PAD = 576;  // columns of slack either side of a row: whole-wave vector loads stay inside it
 
 // per-pair status (allwave_hip.h AWV_ST_*)
@@ -150,7 +157,6 @@ struct Lds {
 };
 struct Shared {
   Acc acc[3][2];
-  Task stack[STACK_CAP];
   int ext0[2];
   unsigned long long prof[5];
   long long cur_pair;
@@ -186,6 +192,14 @@ __device__ __forceinline__ bool row_empty(const RowMeta& m) { return m.lo > m.hi
 // arrive in vector registers; readfirstlane moves them to SGPRs so the step planning, row offsets
 // and control flow run on the scalar unit (and stop eating the VGPR budget).
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// threadIdx.x for the cold phases: opaque, so that what is derived from it (strided loop counters,
+// per-thread pointers) is recomputed there instead of being hoisted into registers that stay
+// allocated across the hot row loop
+__device__ __forceinline__ int cold_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
 __device__ __forceinline__ RowMeta uni(const RowMeta& m) { return RowMeta{uni(m.lo), uni(m.hi)}; }
 
 __device__ __forceinline__ uint64_t ld64u(gseq_t p) {
@@ -405,8 +419,9 @@ __device__ __forceinline__ void stage_sequences(const KParams& kp, const Lds<Off
   const int total_words = cx.t_w0 + ntw + 3;
   if (total_words * 4 > kp.lds_seq_bytes) return;
   cx.seq_mode = 1;
-  for (int i = threadIdx.x; i < npw; i += WG) lds.seq[cx.p_w0 + i] = cx.Pw[pw_first + i];
-  for (int i = threadIdx.x; i < ntw; i += WG) lds.seq[cx.t_w0 + i] = cx.Tw[tw_first + i];
+  const int t0 = cold_tid();
+  for (int i = t0; i < npw; i += WG) lds.seq[cx.p_w0 + i] = cx.Pw[pw_first + i];
+  for (int i = t0; i < ntw; i += WG) lds.seq[cx.t_w0 + i] = cx.Tw[tw_first + i];
   __syncthreads();
 }
 
@@ -936,7 +951,7 @@ struct Emit {
 __device__ __forceinline__ int op_index(uint8_t op) { return op == 'M' ? 0 : op == 'X' ? 1 : op == 'I' ? 2 : 3; }
 __device__ __forceinline__ void emit_run(Emit& em, uint8_t op, int len) {
   uint8_t* p = em.cig + em.n;
-  for (int i = threadIdx.x; i < len; i += WG) p[i] = op;
+  for (int i = cold_tid(); i < len; i += WG) p[i] = op;
   em.n += len;
   em.cnt[0] += op == 'M' ? len : 0;
   em.cnt[1] += op == 'X' ? len : 0;
@@ -964,7 +979,7 @@ template <bool P2, typename OffT>
 __device__ int base_align(const KParams& kp, Shared& sh, const Lds<OffT>& lds, SubCtx cx, void* hist_mem, rsrc_t hist_rs, uint32_t* events,
                           int cb, int ce, Emit& em, int& penalty_out, unsigned long long* lstats) {
   const DevPenalties& pn = kp.pen;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = cold_tid(), lane = tid & 63;
   const int plen = cx.plen, tlen = cx.tlen;
   OffT* hist = (OffT*)hist_mem;
   const RowMeta* base_meta = lds.meta_log;  // HBM log, written by plan_step / finalize_row
@@ -1155,7 +1170,7 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
   constexpr int WSPAN = 64 * VEC;
   const DevPenalties& pn = kp.pen;
   const int d1 = 1 - d0;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = cold_tid(), lane = tid & 63, wave = tid >> 6;
   const int rmask = kp.ring - 1;
   const int plen = cx.plen, tlen = cx.tlen, L = plen + tlen, D = tlen - plen;
   const int slot0 = s0 & rmask;
@@ -1330,7 +1345,7 @@ template <bool P2, typename OffT>
 __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& lds, SubCtx cx, void* ring_mem, rsrc_t ring_rs, int cb, int ce,
                                int score_remaining, Breakpoint& bp, unsigned long long* lstats) {
   const DevPenalties& pn = kp.pen;
-  const int tid = threadIdx.x;
+  const int tid = cold_tid();
   const int plen = cx.plen, tlen = cx.tlen;
   const int rmask = kp.ring - 1;
   // column spaces: forward kmin, reverse kmin mirrored on chunk boundaries (C == 63 mod 64)
@@ -1479,9 +1494,10 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
 // The kernel: persistent workgroups, one pair at a time, DFS over the BiWFA recursion
 // ---------------------------------------------------------------------------------------------
 template <bool P2, typename OffT>
-__global__ __launch_bounds__(WG, 4) void biwfa_align_kernel(KParams kp) {
+__global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams kp) {
   __shared__ Shared sh;
   __shared__ unsigned long long lstats[STAT_N];
+  static_assert(sizeof(Shared) + sizeof(unsigned long long) * STAT_N <= STATIC_LDS_RESERVE, "static LDS reserve");
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   Lds<OffT> lds;
   typedef typename MetaTraits<OffT>::Stored MetaStored;
@@ -1490,11 +1506,12 @@ __global__ __launch_bounds__(WG, 4) void biwfa_align_kernel(KParams kp) {
   lds.bi_oob = lds.bi_A + 2 * kp.ring;
   lds.firstk = lds.bi_oob + 2 * kp.ring;
   lds.seq = reinterpret_cast<uint32_t*>(dyn_smem + kp.lds_meta_bytes);
-  const int tid = threadIdx.x;
+  const int tid = cold_tid();
   const DevPenalties& pn = kp.pen;
   void* ring_mem = (char*)kp.ring_mem + (size_t)blockIdx.x * kp.ring_slot_stride;
   void* hist = (char*)kp.hist_mem + (size_t)blockIdx.x * kp.hist_slot_stride;
   uint32_t* events = kp.ev_mem + (size_t)blockIdx.x * kp.ev_slot_stride;
+  Task* const stack = reinterpret_cast<Task*>(events + kp.wcap);  // the DFS stack lives behind the events (HBM; touched once per sub-problem)
   const rsrc_t ring_rs = make_rsrc(ring_mem, kp.ring_slot_stride);
   const rsrc_t hist_rs = make_rsrc(hist, kp.hist_slot_stride);
   lds.meta_log = reinterpret_cast<RowMeta*>((char*)hist + kp.hist_meta_offset);
@@ -1535,13 +1552,13 @@ __global__ __launch_bounds__(WG, 4) void biwfa_align_kernel(KParams kp) {
     int sp = 0;
     if (tid == 0) {
       const bool min_length = max(plenT, tlenT) <= FALLBACK_MIN_LENGTH;
-      sh.stack[0] = Task{0, plenT, 0, tlenT, C_M, C_M, min_length ? 0 : INT_MAX};
+      stack[0] = Task{0, plenT, 0, tlenT, C_M, C_M, min_length ? 0 : INT_MAX};
     }
     sp = 1;
     __syncthreads();
     bool top = true;
     while (sp > 0 && status == ST_OK) {
-      Task t = sh.stack[sp - 1];
+      Task t = stack[sp - 1];
       t.pb = uni(t.pb); t.pe = uni(t.pe); t.tb = uni(t.tb); t.te = uni(t.te);
       t.cb = uni(t.cb); t.ce = uni(t.ce); t.score_remaining = uni(t.score_remaining);
       --sp;
@@ -1590,8 +1607,8 @@ __global__ __launch_bounds__(WG, 4) void biwfa_align_kernel(KParams kp) {
       const int bh = bp.off_f, bv = bp.off_f - bp.kf;
       if (bh < 0 || bh > tlen || bv < 0 || bv > plen || sp + 2 > STACK_CAP) { status = ST_INTERNAL; break; }
       if (tid == 0) {
-        sh.stack[sp] = Task{t.pb + bv, t.pe, t.tb + bh, t.te, bp.comp, t.ce, bp.sr};      // right half
-        sh.stack[sp + 1] = Task{t.pb, t.pb + bv, t.tb, t.tb + bh, t.cb, bp.comp, bp.sf};  // left half first
+        stack[sp] = Task{t.pb + bv, t.pe, t.tb + bh, t.te, bp.comp, t.ce, bp.sr};      // right half
+        stack[sp + 1] = Task{t.pb, t.pb + bv, t.tb, t.tb + bh, t.cb, bp.comp, bp.sf};  // left half first
       }
       sp += 2;
       if (top) penalty = bp.score;

@@ -15,6 +15,7 @@
 #include <vector>
 
 namespace {
+constexpr size_t EV_EXTRA = (awv::STACK_CAP * sizeof(awv::Task) + 3) / 4 + 16;  // uint32 words behind the events: the DFS stack
 
 thread_local std::string g_last_error;
 
@@ -238,7 +239,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   }
   int ring = 4;
   while (ring < dp.scope + 2) ring *= 2;
-  const int nslots_cfg = e->cfg.workgroups > 0 ? e->cfg.workgroups : (1024 / WG) * e->num_cus;
+  const int nslots_cfg = e->cfg.workgroups > 0 ? e->cfg.workgroups : (WAVES_PER_SIMD * 256 / WG) * e->num_cus;
   const int64_t max_batch = e->cfg.max_batch_pairs > 0 ? e->cfg.max_batch_pairs : (int64_t)1 << 20;
   const uint64_t max_arena = e->cfg.max_arena_bytes > 0 ? (uint64_t)e->cfg.max_arena_bytes : (uint64_t)8 << 30;
   // base-case capacities: score_remaining <= 250 or both lengths <= 100
@@ -319,7 +320,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     // sub-problems that do not fit read global memory instead
     const size_t lds_meta = lds_meta_bytes(narrow ? sizeof(RowMeta16) : sizeof(RowMeta));
     const size_t seq_need = ((((size_t)maxlen + 15) / 16 + 2) * 2 + 10) * 4;
-    const size_t lds_budget = (size_t)(160 * 1024 / (1024 / WG)) - 2048;
+    const size_t lds_budget = (size_t)(160 * 1024 / (WAVES_PER_SIMD * 256 / WG)) - STATIC_LDS_RESERVE;
     size_t lds_seq = (e->cfg.flags & AWV_F_NO_PACKED_SEQ) ? 0 : (lds_meta < lds_budget ? std::min(seq_need, lds_budget - lds_meta) : 0);
     lds_seq &= ~(size_t)15;
     const size_t dyn_lds = lds_meta + lds_seq;
@@ -328,7 +329,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     // per-workgroup arenas as a function of the row capacity (columns)
     const size_t budget = e->cfg.max_scratch_bytes > 0 ? (size_t)e->cfg.max_scratch_bytes : (size_t)160 << 30;
     auto per_slot = [&](int wc) {
-      return (size_t)2 * NCOMP * ring * wc * esz + hist_stride + (size_t)wc * sizeof(uint32_t) +
+      return (size_t)2 * NCOMP * ring * wc * esz + hist_stride + (size_t)(wc + EV_EXTRA) * sizeof(uint32_t) +
              (size_t)2 * ring * (wc / 256 + 2) * sizeof(int);
     };
     // Row capacity of the first attempt.  A wavefront at score s spans at most ~2 s / min(e) diagonals,
@@ -360,7 +361,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     for (int wc = wcap;;) {
       const int64_t m = (int64_t)hq.size();
       const size_t ring_stride = (size_t)2 * NCOMP * ring * wc * esz;
-      const size_t ev_stride = (size_t)wc;
+      const size_t ev_stride = (size_t)wc + EV_EXTRA;  // run-length events + the DFS stack
       const int chunks_cap = wc / 256 + 2;
       const size_t chunk_stride = (size_t)2 * ring * chunks_cap;
       int nslots = (int)std::min<int64_t>(nslots_cfg, m);
