@@ -226,3 +226,16 @@ def test_narrow_first_attempt_is_rerun_with_wider_rows(oracle, monkeypatch):
         assert st.launches >= 2 and st.pairs_completed == len(pairs)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("scores", [(0, 6, 10, 3, 70, 2), (0, 80, 5, 2), (0, 3, 90, 1), (0, 9, 3, 7, 30, 5)])
+def test_wide_scope_penalties(engine, oracle, scores):
+    """Penalty sets whose lookback (scope = max(x, o1+e1, o2+e2) + 1) exceeds one wave's 64 lanes or
+    the LDS staging budget: deeper rings, the row filter of the overlap search in several blocks."""
+    rng = random.Random(hash(scores) & 0xFFFF)
+    seqs, pairs = [], []
+    for _ in range(14):
+        s, t = random_pair(rng, 3500)
+        seqs += [s, t]
+        pairs.append((len(seqs) - 2, len(seqs) - 1))
+    check_against_oracle(engine, oracle, seqs, pairs, scores)
