@@ -1,6 +1,6 @@
 """Multi-GPU plumbing: one process per GPU, pairs sharded with no collective on the data path
-(SURVEY.md 8e); torch.distributed (RCCL on GPUs, gloo on CPUs) only carries the timing barrier and
-the final reduction of counters."""
+(SURVEY.md 8e); torch.distributed (RCCL on GPUs, gloo on CPUs) only carries the timing barrier, the
+final reduction of counters and -- optionally -- the gather of each rank's PAF text on rank 0."""
 import os
 
 import numpy as np
@@ -54,3 +54,26 @@ def reduce_max_sum(dist, elapsed, sums):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     return float(t[0]), [float(x) for x in s]
+
+
+def gather_bytes(dist, payload, local_rank=0):
+    """Optional result gather (BASELINE north_star: "RCCL over xGMI only for optional result gather"):
+    every rank contributes a byte string (its PAF text); rank 0 gets the list in rank order, other
+    ranks get None.  Two collectives: an all-gather of the sizes, then one of the padded payloads."""
+    if dist is None:
+        return [bytes(payload)]
+    import torch
+    dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
+    world = dist.get_world_size()
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([len(payload)], dtype=torch.int64, device=dev))
+    cap = max(int(sizes.max()), 1)
+    mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    if len(payload):
+        mine[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
+    allb = torch.empty(world * cap, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(allb, mine)
+    if dist.get_rank() != 0:
+        return None
+    host = allb.cpu().numpy()
+    return [host[r * cap:r * cap + int(sizes[r])].tobytes() for r in range(world)]

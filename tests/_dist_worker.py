@@ -25,8 +25,14 @@ def main():
     D.barrier(dist)
     bp = sum(int(offs[a + 1] - offs[a]) for a, _ in mine)
     tmax, (bp_all, n_all, pen_all) = D.reduce_max_sum(dist, 0.5 + rank, [bp, len(mine), int(res["penalty"].sum())])
+    # optional result gather: each rank's "PAF text" (here: one line per pair with its penalty)
+    text = "".join("s%05d\ts%05d\t%d\n" % (a, b, p) for (a, b), p in zip(mine, res["penalty"])).encode()
+    parts = D.gather_bytes(dist, text)
     if rank == 0:
-        json.dump(dict(world=world, tmax=tmax, bp=bp_all, n=n_all, pen=pen_all), open(out_path, "w"))
+        lines = sorted(b"".join(parts).decode().splitlines())
+        json.dump(dict(world=world, tmax=tmax, bp=bp_all, n=n_all, pen=pen_all, lines=lines), open(out_path, "w"))
+    else:
+        assert parts is None
     if dist is not None:
         dist.destroy_process_group()
 

@@ -42,3 +42,5 @@ def test_two_ranks_equal_one(tmp_path):
     assert two["world"] == 2 and one["world"] == 1
     assert (two["bp"], two["n"], two["pen"]) == (one["bp"], one["n"], one["pen"])
     assert two["tmax"] == 1.5  # max over ranks of the per-rank timer
+    # the gathered per-rank texts together are the single-process text
+    assert two["lines"] == one["lines"] and len(one["lines"]) == one["n"]
