@@ -98,6 +98,9 @@ int64_t awo_gotoh_penalty(const uint8_t* pattern, int plen, const uint8_t* text,
 int awo_cigar_check(const uint8_t* cigar, int n, const uint8_t* pattern, int plen,
                     const uint8_t* text, int tlen, const awo_penalties_t* pen, int64_t* rescored);
 
+/* FNV-1a over op bytes (the per-pair hash of awo_all_pairs) */
+uint64_t awo_fnv1a(const uint8_t* p, int64_t n);
+
 /* ---- oracle/allpairs_cpu.c : rayon-like all-pairs driver (iterator.rs:222-233) ---- */
 typedef struct {
   int32_t status, penalty, cigar_len;

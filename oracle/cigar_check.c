@@ -59,3 +59,11 @@ int awo_cigar_check(const uint8_t* cigar, int n, const uint8_t* pattern, int ple
   if (rescored) *rescored = score;
   return 0;
 }
+
+/* FNV-1a over op bytes: the hash awo_all_pairs reports per pair (allpairs_cpu.c), exposed so that a
+ * test can hash the bytes another implementation produced and compare without a Python byte loop. */
+uint64_t awo_fnv1a(const uint8_t* p, int64_t n) {
+  uint64_t h = 1469598103934665603ULL;
+  for (int64_t i = 0; i < n; ++i) h = (h ^ p[i]) * 1099511628211ULL;
+  return h;
+}

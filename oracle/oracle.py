@@ -78,6 +78,8 @@ def lib():
             fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(Penalties), C.c_int,
                            C.c_void_p, C.POINTER(Stats), C.POINTER(C.c_uint64)]
         L.awo_aligner_set_fast_overlap.argtypes = [C.c_void_p, C.c_int]
+        L.awo_fnv1a.restype = C.c_uint64
+        L.awo_fnv1a.argtypes = [C.c_char_p, C.c_int64]
         _LIB = L
     return _LIB
 
@@ -134,6 +136,12 @@ def cigar_check(cigar, pattern, text, scores):
     rc = lib().awo_cigar_check(cigar, len(cigar), pattern, len(pattern), text, len(text), C.byref(pen),
                                C.byref(out))
     return rc, out.value
+
+
+def fnv1a(data):
+    """FNV-1a of a byte string (the per-pair CIGAR hash all_pairs() reports)."""
+    data = bytes(data)
+    return lib().awo_fnv1a(data, len(data))
 
 
 def all_pairs(seqs, offsets, pairs, scores, nthreads=1, want_paf=False, fast_overlap=False):
