@@ -219,12 +219,13 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row storage: OffT = int16_t (8 diagonals per 16-byte lane vector; used when every offset fits,
-// i.e. text length < 32760) or int32_t (4 per vector).  Arithmetic is always int32 in registers
-// with WFA2's NULL = INT32_MIN/2 (A.1).  int16 rows store NULL(+n) as -1 and clamp offsets past
-// the text end to tlen+1: both are invisible to every comparison the algorithm makes (a NULL(+n)
-// only ever meets max() against real offsets or the out-of-bounds test; an h > tlen offset stays
-// out of bounds under +1 / diagonal shifts and only ever wins max() or fails the bounds test).
+// Row storage: OffT = int16_t (used when every offset fits, i.e. lengths < 32760) or int32_t; a lane
+// vector is 4 diagonals (8 or 16 bytes).  32-bit rows compute in int32 with WFA2's NULL =
+// INT32_MIN/2 (A.1); 16-bit rows compute on packed halves.  16-bit rows store every NULL(+n) as
+// NULL16 = -16384 and clamp offsets past the text end to tlen+1: both are invisible to every
+// comparison the algorithm makes (a NULL(+n) only ever meets max() against real offsets or the
+// out-of-bounds test; an h > tlen offset stays out of bounds under +1 / diagonal shifts and only
+// ever wins max() or fails the bounds test).
 // ---------------------------------------------------------------------------------------------
 template <typename OffT> struct OffTraits;
 template <> struct OffTraits<int32_t> { static constexpr int VEC = 4; };
@@ -237,40 +238,11 @@ __device__ __forceinline__ int32_t off_load1(const OffT* p) {
   return v;
 }
 
-template <typename OffT, int VEC>
-__device__ __forceinline__ void off_load_vec(const OffT* p, int32_t (&out)[VEC]) {
-  OffT tmp[VEC];
-  __builtin_memcpy(tmp, p, sizeof(tmp));  // one 16-byte load (element-aligned only)
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) {
-    const int32_t v = (int32_t)tmp[j];
-    out[j] = (sizeof(OffT) == 2 && v < 0) ? OFF_NULL : v;
-  }
-}
-
 // Buffer addressing for the hot row accesses: one SGPR descriptor per arena, an SGPR byte offset
 // per row, one shared VGPR column offset per lane and the k-1/k/k+1 shift as an immediate.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(void* p, size_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)min(bytes, (size_t)0x7FFFFFFF), 0x00020000);
-}
-
-template <typename OffT>
-__device__ __forceinline__ void buf_load_vec(rsrc_t r, int voff, int soff, int32_t (&out)[4]) {
-  if (sizeof(OffT) == 2) {
-    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    const int32_t a = (int32_t)raw[0], b = (int32_t)raw[1];
-    out[0] = (a << 16) >> 16;
-    out[1] = a >> 16;
-    out[2] = (b << 16) >> 16;
-    out[3] = b >> 16;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = out[j] < 0 ? OFF_NULL : out[j];
-  } else {
-    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = (int32_t)raw[j];
-  }
 }
 
 template <typename OffT> struct RawVec;
@@ -331,17 +303,6 @@ __device__ __forceinline__ int row_off(const KParams& kp, int dir, int comp, int
   if (BASE) return (int)(((unsigned)score * NCOMP + comp) * (unsigned)kp.wb_cap * (unsigned)sizeof(OffT));
   return (int)((((unsigned)(dir * NCOMP + comp)) * kp.ring + (unsigned)(score & (kp.ring - 1))) * (unsigned)kp.wcap *
                (unsigned)sizeof(OffT));
-}
-
-template <typename OffT, int VEC>
-__device__ __forceinline__ void off_store_vec(OffT* p, const int32_t (&v)[VEC], int tlen) {
-  OffT tmp[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) {
-    if (sizeof(OffT) == 2) tmp[j] = (OffT)(v[j] < 0 ? NULL16 : min(v[j], tlen + 1));
-    else tmp[j] = (OffT)v[j];
-  }
-  __builtin_memcpy(p, tmp, sizeof(tmp));
 }
 
 // bounded LCP of pattern[v..] / text[h..] (A.4), 8 bytes per iteration
@@ -948,7 +909,6 @@ struct Emit {
   int n;
   int cnt[4];  // M X I D
 };
-__device__ __forceinline__ int op_index(uint8_t op) { return op == 'M' ? 0 : op == 'X' ? 1 : op == 'I' ? 2 : 3; }
 __device__ __forceinline__ void emit_run(Emit& em, uint8_t op, int len) {
   uint8_t* p = em.cig + em.n;
   for (int i = cold_tid(); i < len; i += WG) p[i] = op;
