@@ -192,6 +192,12 @@ __device__ __forceinline__ bool row_empty(const RowMeta& m) { return m.lo > m.hi
 // arrive in vector registers; readfirstlane moves them to SGPRs so the step planning, row offsets
 // and control flow run on the scalar unit (and stop eating the VGPR budget).
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// clamp(x, -1, hi) for hi >= -1 in one instruction (the compiler cannot prove -1 <= hi for a runtime bound)
+__device__ __forceinline__ int clamp_from_m1(int x, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(x), "s"(hi));
+  return r;
+}
 // threadIdx.x for the cold phases: opaque, so that what is derived from it (strided loop counters,
 // per-thread pointers) is recomputed there instead of being hoisted into registers that stay
 // allocated across the hot row loop
@@ -338,6 +344,24 @@ __device__ __forceinline__ uint64_t lds_bits64(const uint32_t* base, int pos) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// 16-base version for the first probe of a cell: most cells stop within a few bases, and the
+// occasional longer run continues with the 32-base probes of extend_lcp_packed
+constexpr int PROBE_FIRST = 16;
+__device__ __forceinline__ unsigned lds_bits32(const uint32_t* base, int pos) {
+  const uint32_t* w = base + (pos >> 4);
+  return __builtin_amdgcn_alignbit(w[1], w[0], ((unsigned)pos & 15u) * 2u);
+}
+template <int DIR>
+__device__ __forceinline__ int packed_first_count(const uint32_t* seq, const SubCtx& cx, int v, int h) {
+  if (DIR == 0) {
+    const unsigned x = lds_bits32(seq + cx.p_w0, cx.p_bit + v) ^ lds_bits32(seq + cx.t_w0, cx.t_bit + h);
+    return x == 0 ? PROBE_FIRST : (int)(__builtin_ctz(x) >> 1);
+  }
+  // the 16 bases that END at forward position (len - v): start = bit + len - v - 16, biased by one pad word
+  const unsigned x = lds_bits32(seq + cx.p_w0 - 1, cx.p_bit + cx.plen - v) ^ lds_bits32(seq + cx.t_w0 - 1, cx.t_bit + cx.tlen - h);
+  return x == 0 ? PROBE_FIRST : (int)(__builtin_clz(x) >> 1);
+}
+
 // XOR of the next 32 pattern/text bases at (v, h) of direction DIR
 template <int DIR>
 __device__ __forceinline__ uint64_t packed_probe(const uint32_t* seq, const SubCtx& cx, int v, int h) {
@@ -479,8 +503,9 @@ __device__ __forceinline__ void plan_step(const KParams& kp, const Lds<OffT>& ld
 // k0..k0+3; shift_from_left gives k0-1..k0+2 (the missing element is lane l-1's last one), and
 // shift_from_right gives k0+1..k0+4 (lane l+1's first one).  Full-wave DPP shifts (wave_shr:1 /
 // wave_shl:1) move the halo element; lanes 0 / 63 receive nothing useful and are not productive.
-__device__ __forceinline__ unsigned dpp_from_lower_lane(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ unsigned dpp_from_upper_lane(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+// (bound_ctrl on: the lane without a source reads 0 and no "old" value has to be materialised)
+__device__ __forceinline__ unsigned dpp_from_lower_lane(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned dpp_from_upper_lane(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true); }
 __device__ __forceinline__ RawVec<int16_t> shift_from_left(const RawVec<int16_t>& c) {
   RawVec<int16_t> o;
   o.w[0] = __builtin_amdgcn_alignbit(c.w[0], dpp_from_lower_lane(c.w[1]), 16);
@@ -691,7 +716,7 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int mm = (int)mm2[e];
-          const int hmax = max(min(hbase + 2 * r + e, tlen), -1);
+          const int hmax = clamp_from_m1(hbase + 2 * r + e, tlen);
           lane_oob |= lane_on && mm > hmax;
           m[2 * r + e] = (mm > hmax || mm < 0 || !lane_on) ? OFF_NULL : mm;
         }
@@ -726,7 +751,7 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
         const int32_t mm = max(del, max((int32_t)cMx.w[j] + 1, ins));
         // in-bounds <=> 0 <= value <= hmax.  mm is the max of the cell's five values, so "some
         // non-NULL value of this cell is out of bounds" <=> mm > hmax (any negative is a NULL(+n)).
-        const int hmax = max(min(hbase + j, tlen), -1);
+        const int hmax = clamp_from_m1(hbase + j, tlen);
         lane_oob |= lane_on && mm > hmax;
         m[j] = (mm > hmax || mm < 0 || !lane_on) ? OFF_NULL : mm;
       }
@@ -742,8 +767,8 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_ALU, tc1);
     const unsigned long long tc2 = PROF_NOW();
-    // extend (A.4): the first probe of all four cells is issued together (invalid cells probe offset
-    // 0, always readable), then the rare long runs continue in a loop
+    // extend (A.4): the first probe (16 bases) of all four cells is issued together (invalid cells
+    // probe offset 0, always readable), then the longer runs continue in a loop
     int rr[VEC], vv[VEC], hh[VEC];
     uint64_t xx[VEC];
     const bool packed = cx.seq_mode != 0;
@@ -758,18 +783,18 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     // uniform branches hoisted out of the per-cell code so the four probes stay back to back
     int cont = 0;
     if (packed) {
+      int nn[VEC];
       if (dir == 0) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) xx[j] = packed_probe<0>(seq, cx, vv[j], hh[j]);
+        for (int j = 0; j < VEC; ++j) nn[j] = packed_first_count<0>(seq, cx, vv[j], hh[j]);
       } else {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) xx[j] = packed_probe<1>(seq, cx, vv[j], hh[j]);
+        for (int j = 0; j < VEC; ++j) nn[j] = packed_first_count<1>(seq, cx, vv[j], hh[j]);
       }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        int n = dir == 0 ? packed_count<0>(xx[j]) : packed_count<1>(xx[j]);
-        cont |= (n == PROBE_PACKED && rr[j] > PROBE_PACKED) ? (1 << j) : 0;
-        m[j] += min(n, rr[j]);  // rr == 0 for NULL cells: unchanged
+        cont |= (nn[j] == PROBE_FIRST && rr[j] > PROBE_FIRST) ? (1 << j) : 0;
+        m[j] += min(nn[j], rr[j]);  // rr == 0 for NULL cells: unchanged
       }
     } else {
 #pragma unroll
