@@ -355,11 +355,11 @@ template <int DIR>
 __device__ __forceinline__ int packed_first_count(const uint32_t* seq, const SubCtx& cx, int v, int h) {
   if (DIR == 0) {
     const unsigned x = lds_bits32(seq + cx.p_w0, cx.p_bit + v) ^ lds_bits32(seq + cx.t_w0, cx.t_bit + h);
-    return x == 0 ? PROBE_FIRST : (int)(__builtin_ctz(x) >> 1);
+    return (x ? __builtin_ctz(x) : 32) >> 1;  // (v_ffbl + v_min: 16 when all sixteen bases match)
   }
   // the 16 bases that END at forward position (len - v): start = bit + len - v - 16, biased by one pad word
   const unsigned x = lds_bits32(seq + cx.p_w0 - 1, cx.p_bit + cx.plen - v) ^ lds_bits32(seq + cx.t_w0 - 1, cx.t_bit + cx.tlen - h);
-  return x == 0 ? PROBE_FIRST : (int)(__builtin_clz(x) >> 1);
+  return (x ? __builtin_clz(x) : 32) >> 1;
 }
 
 // XOR of the next 32 pattern/text bases at (v, h) of direction DIR
@@ -1235,6 +1235,12 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
       chhi = max(chhi, cbn[c] >> 8);
     }
     if (!live) return;
+    // M-row gate: on every diagonal an in-bounds I/D offset is <= the M offset of the same score, so a
+    // chunk whose two M rows nowhere reach h0 + h1 >= tlen holds no overlap of any component.  Two
+    // loads decide that before the other components' rows are touched.  (Not with out-of-bounds
+    // values around: their M cells are stored as NULL while the I/D cells keep the value.)
+    const bool m_gate = !oob0 && !uni(lds.bi_oob[d1 * kp.ring + (si & rmask)]);
+    const int so0M = row_off<false, OffT>(kp, d0, C_M, s0), so1M = row_off<false, OffT>(kp, d1, C_M, si);
     int nth = 0;  // waves take the candidate chunks round-robin, each in ascending order
     for (int ch = chlo; ch <= chhi && live; ++ch) {
       if (ch < 64 && !((cmask >> ch) & 1ull)) continue;  // (chunks >= 64 are not filtered)
@@ -1247,6 +1253,15 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
       if (tid == 0) lstats[STAT_OVERLAP] += (unsigned long long)__builtin_popcount(here);
       const int cbase = ch << 8;
       const int c0 = cbase + lane * VEC;
+      if (m_gate) {
+        int32_t g0[VEC], g1[VEC];
+        unpack_raw<OffT>(buf_load_raw<OffT>(ring_rs, c0 * ESZ, so0M), g0);
+        unpack_raw<OffT>(buf_load_raw<OffT>(ring_rs, (Cm - c0 - (VEC - 1)) * ESZ, so1M), g1);
+        bool reach = false;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) reach = reach || (g0[j] >= 0 && g1[VEC - 1 - j] >= 0 && g0[j] + g1[VEC - 1 - j] >= tlen);
+        if (__ballot(reach) == 0) continue;
+      }
       RawVec<OffT> q0[NCOMP], q1[NCOMP];
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) {

@@ -9,6 +9,5 @@ n = 4096
 res,_ = e.align_pairs((0,5,8,2,24,1), pairs[:n], want_cigars=False)
 st = e.stats()
 p = list(st.prof)
-print("pairs", n, "cells/pair %.3e" % (st.cell_steps/n), "ext_probes/pair %.3e" % (st.extend_steps/n), "bp/pair %.1f base/pair %.1f ovscans/pair %.1f passes/pair %.1f" % (st.n_breakpoints/n, st.n_base/n, st.overlap_scans/n, p[8]/n))
-print("windows/pair %.1f interior %.1f cont_windows %.1f cont_lanes %.1f rows/pair %.1f" % (p[12]/n, p[9]/n, p[10]/n, p[11]/n, p[13]/n))
-print("cells/window %.1f  probes/window %.2f" % (st.cell_steps/max(p[12],1), st.extend_steps/max(p[12],1)))
+print("pairs", n, "cells/pair %.3e" % (st.cell_steps/n), "bp/pair %.1f base/pair %.1f passes/pair %.1f" % (st.n_breakpoints/n, st.n_base/n, p[8]/n))
+print("per pair: counters", ["%.1f" % (x/n) for x in p[9:14]])
