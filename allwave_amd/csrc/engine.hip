@@ -8,6 +8,7 @@
 #include "biwfa_device.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -256,6 +257,11 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
            ~(size_t)15;
   };
 
+  const bool timing = getenv("AWV_TIMING") != nullptr;  // diagnostic: host-side stage times on stderr
+  const auto tl0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (timing) fprintf(stderr, "[awv] %-22s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count());
+  };
   std::vector<int32_t> hq, ht, hrc;
   std::vector<uint64_t> hoff;
   std::vector<awv_result> hres;
@@ -336,14 +342,17 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     // far fewer than plen + tlen for similar sequences; when full-width rows would not leave room for
     // every workgroup's arenas (long sequences), start with the widest rows that do and re-run only
     // the pairs whose wavefronts outgrow them (status CAPACITY) with wider rows.
-    int wcap = wcap_full;
-    if (per_slot(wcap_full) * (size_t)nslots_want > budget) {
+    // Half-width rows (at least 8192 columns) already hold every pair whose optimal score is below
+    // about a quarter of plen + tlen; they halve the arenas (allocating -- and the driver clearing --
+    // tens of GB is the largest fixed cost of a call) and only unusually divergent pairs are re-run.
+    int wcap = std::min(wcap_full, std::max(8192, (wcap_full / 2 + 255) & ~255));
+    if (per_slot(wcap) * (size_t)nslots_want > budget) {
       const size_t fixed = hist_stride + 2 * (size_t)2 * ring * sizeof(int);
       const size_t per_col = (size_t)2 * NCOMP * ring * esz + sizeof(uint32_t) + (size_t)2 * ring * sizeof(int) / 256 + 1;
       const size_t share = budget / (size_t)nslots_want;
       long long wc = share > fixed ? (long long)((share - fixed) / per_col) : 0;
       wc = std::max<long long>(wc & ~255LL, 8192);
-      wcap = (int)std::min<long long>(wcap_full, wc);
+      wcap = (int)std::min<long long>(wcap, wc);
     }
     if (const char* env = getenv("AWV_WCAP_MAX")) wcap = std::min(wcap, std::max(2048, atoi(env)));  // experiment knob
     if (int rc = e->d_pair_q.reserve((size_t)n)) return rc;
@@ -373,6 +382,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       if (int rc = e->hist_mem.reserve(hist_stride * nslots)) return rc;
       if (int rc = e->ev_mem.reserve(ev_stride * nslots)) return rc;
       if (int rc = e->chunk_mem.reserve(chunk_stride * nslots)) return rc;
+      lap("arenas reserved");
       // ---- H2D
       HIP_TRY(hipEventRecord(e->ev0, e->stream));
       HIP_TRY(hipMemcpyAsync(e->d_pair_q.p, hq.data(), (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
@@ -435,6 +445,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
       kernel_ms += ms;
       ++launches;
+      lap("kernel done");
       // ---- D2H (results + counters)
       tres.resize((size_t)m);
       HIP_TRY(hipEventRecord(e->ev0, e->stream));
@@ -468,8 +479,10 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       wc = (int)std::min<long long>(wcap_full, 4LL * wc);
     }
     const bool want_cigar = sink && !(e->cfg.flags & AWV_F_KEEP_ON_DEVICE);
+    lap("results on host");
     if (want_cigar) {
       e->h_cigar.resize((size_t)arena + 64);
+      lap("host cigar buffer");
       HIP_TRY(hipEventRecord(e->ev0, e->stream));
       HIP_TRY(hipMemcpyAsync(e->h_cigar.data(), e->d_cigar.p, (size_t)arena, hipMemcpyDeviceToHost, e->stream));
       HIP_TRY(hipEventRecord(e->ev1, e->stream));
@@ -477,10 +490,12 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
       d2h_ms += ms;
     }
+    lap("cigars on host");
     if (out) std::memcpy(out + first, hres.data(), (size_t)n * sizeof(awv_result));
     if (sink) {
       const int rc = sink(user, first, n, hres.data(), want_cigar ? e->h_cigar.data() : nullptr);
       if (rc != 0) return fail(AWV_ERR_SINK, "sink callback returned " + std::to_string(rc));
+      lap("sink returned");
     }
     first += n;
   }

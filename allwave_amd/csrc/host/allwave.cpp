@@ -7,7 +7,10 @@
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <map>
 #include <memory>
+#include <mutex>
+#include <chrono>
 #include <thread>
 
 namespace allwave {
@@ -171,14 +174,32 @@ std::string alignment_to_paf(const AlignmentResult& r, const std::vector<Sequenc
 
 // ---- iterator.rs ----------------------------------------------------------------------------
 namespace {
+// One engine per device and process, created on first use and kept (like the reference's cached
+// per-thread aligners, alignment.rs:11-22): its HBM arenas are tens of GB, and allocating them right
+// after a free can take the driver seconds.  A holder owns the device's engine for its lifetime.
 struct EngineHolder {
   awv_engine* e = nullptr;
+  std::unique_lock<std::mutex> lock;
   explicit EngineHolder(int device) {
-    awv_engine_config cfg{};
-    cfg.device = device;
-    if (awv_engine_create(&cfg, &e) != AWV_OK) throw AlignmentError(std::string("engine: ") + awv_last_error());
+    static std::mutex mu;                       // guards the table
+    static std::map<int, std::pair<awv_engine*, std::unique_ptr<std::mutex>>> engines;
+    std::mutex* dev_mu;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto& slot = engines[device];
+      if (!slot.second) slot.second.reset(new std::mutex());
+      dev_mu = slot.second.get();
+    }
+    lock = std::unique_lock<std::mutex>(*dev_mu);  // one run at a time per device
+    std::lock_guard<std::mutex> g(mu);
+    auto& slot = engines[device];
+    if (!slot.first) {
+      awv_engine_config cfg{};
+      cfg.device = device;
+      if (awv_engine_create(&cfg, &slot.first) != AWV_OK) throw AlignmentError(std::string("engine: ") + awv_last_error());
+    }
+    e = slot.first;
   }
-  ~EngineHolder() { awv_engine_destroy(e); }
 };
 
 void upload(awv_engine* e, const std::vector<Sequence>& seqs) {
@@ -255,8 +276,15 @@ AllPairIterator& AllPairIterator::with_device(int device) { device_ = device; re
 
 void AllPairIterator::run(const std::function<void(int64_t, int64_t, const awv_result*, const uint8_t*,
                                                    const std::vector<uint8_t>&)>& batch_cb) {
+  const bool timing = getenv("AWH_TIMING") != nullptr;  // diagnostic: stage times on stderr
+  const auto tr0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (timing) fprintf(stderr, "[awh] %-18s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count());
+  };
   EngineHolder eh(device_);
+  lap("engine created");
   upload(eh.e, sequences_);
+  lap("sequences uploaded");
   const int64_t n = (int64_t)pairs_.size();
   std::vector<uint8_t> is_rev((size_t)n, 0);
   std::vector<awv_pair> ap((size_t)n);
@@ -299,7 +327,9 @@ void AllPairIterator::run(const std::function<void(int64_t, int64_t, const awv_r
     return 0;
   };
   const awv_penalties pen = to_penalties(params_);
+  lap("pairs oriented");
   const int rc = awv_align_pairs(eh.e, &pen, ap.data(), n, nullptr, sink, &ctx);
+  lap("aligned + sunk");
   awv_engine_stats(eh.e, &stats_);
   if (ctx.err) std::rethrow_exception(ctx.err);
   if (rc != AWV_OK) throw AlignmentError(std::string("align_pairs: ") + awv_last_error());
@@ -334,6 +364,7 @@ void AllPairIterator::for_each_paf_batch(const std::function<void(const std::str
       });
     }
     for (auto& x : th) x.join();
+    if (getenv("AWH_TIMING")) fprintf(stderr, "[awh] formatted %lld pairs on %d threads\n", (long long)cnt, T);
     for (const auto& p : parts) sink(p);
   });
 }
