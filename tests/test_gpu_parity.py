@@ -239,3 +239,32 @@ def test_wide_scope_penalties(engine, oracle, scores):
         seqs += [s, t]
         pairs.append((len(seqs) - 2, len(seqs) - 1))
     check_against_oracle(engine, oracle, seqs, pairs, scores)
+
+
+def test_config3_shaped_batches():
+    """BASELINE config 3's shape (4096 x 10 kbp, 5 %), a 40 k-pair random slice of its all-pairs list,
+    CIGAR arena capped so that the call takes several launches: every pair completes, the CIGAR
+    consumes both sequences, op counts add up, and penalty(a, b) == penalty(b, a)."""
+    from allwave_amd import ffi, synth
+    cfg = synth.CONFIGS["c3"]
+    data, offs, _ = synth.generate(cfg["nseq"], cfg["length"], cfg["d"], cfg["seed"])
+    n = 40000
+    rng = np.random.default_rng(3)
+    qi = rng.integers(0, cfg["nseq"], n)
+    ti = (qi + 1 + rng.integers(0, cfg["nseq"] - 1, n)) % cfg["nseq"]
+    pairs = np.stack([qi, ti], axis=1).astype(np.int32)
+    pairs[1::2] = pairs[0::2][:, ::-1]  # odd entries: the swapped even pair
+    e = ffi.Engine(flags=ffi.AWV_F_KEEP_ON_DEVICE, max_arena_bytes=256 << 20)
+    try:
+        e.set_sequences((data, offs))
+        res, _ = e.align_pairs(cfg["scores"], pairs, want_cigars=False)
+        st = e.stats()
+        assert st.launches >= 3 and st.pairs_completed == n
+        assert (res["status"] == 0).all()
+        ql = (offs[pairs[:, 0] + 1] - offs[pairs[:, 0]]).astype(np.int64)
+        tl = (offs[pairs[:, 1] + 1] - offs[pairs[:, 1]]).astype(np.int64)
+        assert (res["q_end"] == ql).all() and (res["t_end"] == tl).all()
+        assert (res["num_matches"] + res["num_mismatches"] + res["num_ins"] + res["num_del"] == res["cigar_len"]).all()
+        assert (res["penalty"][0::2] == res["penalty"][1::2]).all()
+    finally:
+        e.close()
