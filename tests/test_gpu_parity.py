@@ -268,3 +268,29 @@ def test_config3_shaped_batches():
         assert (res["penalty"][0::2] == res["penalty"][1::2]).all()
     finally:
         e.close()
+
+
+def test_config4_shaped_budgeted_rows(oracle):
+    """BASELINE config 4's regime: 100 kbp at 2 % (32-bit rows, sequences too long to stage in LDS at
+    the top levels) with the scratch budget set so low that full-width rows (plen + tlen columns) do
+    not fit: the first launch runs with budgeted rows, anything that outgrows them is re-run wider."""
+    from allwave_amd import ffi, synth
+    data, offs, _ = synth.generate(3, 100000, 0.02, 4)
+    seqs = [bytes(data[offs[i]:offs[i + 1]]) for i in range(3)]
+    e = ffi.Engine(max_scratch_bytes=1 << 30)
+    try:
+        check_against_oracle(e, oracle, seqs, [(0, 1), (1, 2), (2, 0)], DEFAULT_2P)
+        assert e.stats().pairs_completed == 3
+    finally:
+        e.close()
+
+
+def test_config5_shaped_sparsified_mixed_lengths(engine, oracle):
+    """BASELINE config 5's shape, scaled down: prefixes of 1-9 kbp of a common root at 10 %, the pair
+    list from the host planner's tree sparsifier (-p tree:3:1:0.1); bit-exact against the oracle."""
+    from allwave_amd import host as H, synth
+    data, offs, ids = synth.generate(20, 9000, 0.10, 5, mixed_lengths=(1000, 9000))
+    seqs = [bytes(data[offs[i]:offs[i + 1]]) for i in range(20)]
+    pairs = [tuple(int(v) for v in p) for p in H.plan_pairs(ids, seqs, "tree:3:1:0.1")]
+    assert 20 <= len(pairs) < 20 * 19
+    check_against_oracle(engine, oracle, seqs, pairs, DEFAULT_2P)
