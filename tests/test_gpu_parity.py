@@ -294,3 +294,14 @@ def test_config5_shaped_sparsified_mixed_lengths(engine, oracle):
     pairs = [tuple(int(v) for v in p) for p in H.plan_pairs(ids, seqs, "tree:3:1:0.1")]
     assert 20 <= len(pairs) < 20 * 19
     check_against_oracle(engine, oracle, seqs, pairs, DEFAULT_2P)
+
+
+@pytest.mark.parametrize("length", [32759, 32760])
+def test_row_width_boundary(engine, oracle, length):
+    """The longest sequences that still use 16-bit rows (32759) and the shortest that take 32-bit
+    rows (32760): offsets, NULL encoding and row metadata at the edge of the 16-bit range."""
+    rng = random.Random(length)
+    a = rand_seq(rng, length)
+    b = mutate(a, 0.03, rng)[:length]
+    b = b + rand_seq(rng, length - len(b))
+    check_against_oracle(engine, oracle, [a, b], [(0, 1), (1, 0)], DEFAULT_2P)
