@@ -5,30 +5,35 @@
 // (/root/reference/src/alignment.rs:231, src/wfa.rs:226) -> WFA2-lib [not in the container;
 // semantics per SURVEY.md Appendix A].  Results are bit-exact against oracle/biwfa_oracle.c.
 //
-// Mapping onto the machine (integer DP: no MFMA):
-//   * one sequence pair per 256-thread workgroup (4 wave64), persistent workgroups pull pairs
-//     from an atomic cursor; the BiWFA recursion is an explicit DFS stack in LDS, so CIGAR ops
-//     come out in order and no device recursion is needed;
-//   * lanes <-> diagonals: a wave owns 64 consecutive diagonals ("chunk") per iteration, all
-//     row loads/stores are coalesced; forward and reverse column spaces are mirrored on chunk
-//     boundaries (colR = C - colF, C == 63 mod 64) so the meet-in-the-middle overlap test reads
-//     both wavefronts coalesced;
-//   * wavefront rows live in a per-workgroup arena in HBM (ring of `ring` rows per component
-//     and direction; L2-resident when hot), row metadata (lo/hi, max antidiagonal) in LDS;
-//   * trimming (first/last in-bounds diagonal) by wave ballots + LDS atomics, max-antidiagonal
-//     by a wave reduction; one workgroup barrier per score step, forward and reverse steps fused.
-#pragma once
+// Mapping onto the machine (integer DP: no MFMA) -- DESIGN.md section 4:
+//   * one sequence pair per workgroup, persistent workgroups pull pairs from an atomic cursor; the
+//     BiWFA recursion is an explicit DFS stack, so CIGAR ops come out in order and no device
+//     recursion is needed;
+//   * lanes <-> diagonals: a lane owns 4 consecutive diagonals, a wave a 256-column window per
+//     iteration; forward and reverse column spaces are mirrored on 256-column chunk boundaries so the
+//     meet-in-the-middle overlap test reads both wavefronts with aligned vector loads;
+//   * wavefront rows live in a per-workgroup arena in HBM (ring of `ring` rows per component and
+//     direction), row metadata (lo/hi, max antidiagonal) in LDS;
+//   * one workgroup barrier per score step, forward and reverse steps fused.
+//
+// The header is compiled once per workgroup size: AWV_WG = 64 (one wave per pair: the throughput
+// kernel) and AWV_WG = 256 (four waves share a pair's rows: small batches and very expensive pairs),
+// each into its own namespace AWV_NS.
+
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
 
-namespace awv {
-
+#ifndef AWV_NS
+#define AWV_NS awv
+#endif
 #ifndef AWV_WG
 #define AWV_WG 64
 #endif
-constexpr int WG = AWV_WG;  // threads per workgroup = per sequence pair (64, 128 or 256)
+namespace AWV_NS {
+
+constexpr int WG = AWV_WG;  // threads per workgroup = per sequence pair (64 or 256)
 constexpr int MAX_RING = 128;
 constexpr int NCOMP = 5;
 constexpr int32_t OFF_NULL = INT32_MIN / 2;
@@ -538,7 +543,8 @@ __device__ __forceinline__ RawVec<int32_t> shift_from_right(const RawVec<int32_t
 template <bool P2, bool BASE, typename OffT>
 __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const Lds<OffT>& lds, const SubCtx& cx, rsrc_t rs,
                                            int dir, int score, const StepPlan& pl, bool dirty, Acc& acc, unsigned& ext_iters) {
-  static_assert(WG == 64, "one wave per pair: a row's windows are walked by a single wave");
+  static_assert(WG % 64 == 0, "whole waves");
+  constexpr int NWAVES = WG / 64;  // a row's windows are dealt round-robin to the workgroup's waves
   constexpr int VEC = OffTraits<OffT>::VEC;
   static_assert(VEC == 4, "lane vectors are 4 diagonals wide");
   constexpr int WSPAN = 64 * VEC;
@@ -594,7 +600,8 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
       int_hi = min(int_hi, ((pl.hull[r].hi - kmin) | (VEC - 1)) - 63 * VEC);
     }
   }
-  for (int cb = (colLo & ~(VEC - 1)) - VEC; cb + VEC <= colHi; cb += WSTRIDE) {  // lane 1 owns columns cb+4..cb+7
+  for (int cb = (colLo & ~(VEC - 1)) - VEC + (NWAVES > 1 ? (int)(threadIdx.x >> 6) * WSTRIDE : 0); cb + VEC <= colHi;
+       cb += WSTRIDE * NWAVES) {  // lane 1 owns columns cb+4..cb+7
     const int c0 = cb + lane * VEC;
     const int k0 = c0 + kmin;
     const int voff = c0 * ESZ;  // naturally aligned lane vector
@@ -824,7 +831,7 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
       if (m[j] >= 0) it_maxak = max(it_maxak, 2 * m[j] - (k0 + j));
-    if (!BASE) {  // chunk maxima for the overlap filter
+    if (!BASE && NWAVES == 1) {  // chunk maxima for the overlap filter (several waves per pair: no chunk filter)
       const int first_col = cb + VEC;                                // column of lane 1
       const int chunk_lo = first_col >> 8;
       const int nlow = (((chunk_lo + 1) << 8) - first_col) / VEC;    // productive lanes 1..nlow lie in chunk_lo
@@ -851,8 +858,8 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     PROF_ADD_L(STAT_T_CR_STORE, tc3);
   }
   const unsigned long long tc4 = PROF_NOW();
-  if (!BASE && cur_chunk >= 0 && lane == 0) ck[cur_chunk] = cur_max;  // the last chunk of the walk
-  const int wmax = BASE ? wave_max_i32(lane_maxak) : lane_maxak;  // (already wave-uniform per window otherwise)
+  if (!BASE && NWAVES == 1 && cur_chunk >= 0 && lane == 0) ck[cur_chunk] = cur_max;  // the last chunk of the walk
+  const int wmax = (BASE || NWAVES > 1) ? wave_max_i32(lane_maxak) : lane_maxak;  // (already wave-uniform per window otherwise)
   const bool woob = __any(lane_oob);
   if (lane == 0) {
     atomicMax(&acc.maxak, wmax);
@@ -1196,6 +1203,7 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
   const int mirror_chunk = (Cm - 255) >> 8;
   const int* ck0 = lds.chunk_ak + ((size_t)d0 * kp.ring + slot0) * kp.chunks_cap;
   auto chunk_mask = [&](int si) -> uint64_t {
+    if (WG > 64) return ~0ull;  // several waves per pair keep no chunk maxima: the M-row gate prunes instead
     if (oob0 || uni(lds.bi_oob[(d1) * kp.ring + (si & rmask)])) return ~0ull;
     const RowMeta m0 = uni(meta_load(&lds.ring_meta[(d0 * NCOMP + C_M) * kp.ring + slot0]));
     const RowMeta m1 = uni(meta_load(&lds.ring_meta[(d1 * NCOMP + C_M) * kp.ring + (si & rmask)]));
@@ -1643,4 +1651,4 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
   if (tid < STAT_N && lstats[tid]) atomicAdd(&kp.stats[tid], lstats[tid]);
 }
 
-}  // namespace awv
+}  // namespace AWV_NS

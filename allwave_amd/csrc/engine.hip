@@ -5,7 +5,17 @@
 // wavefront arenas sized for 288 GB of HBM, result/CIGAR arenas, one stream.  There is no CPU
 // fallback: without a HIP device every entry point fails with AWV_ERR_NO_DEVICE.
 #include "allwave_hip.h"
+// the device code, once per workgroup size: awv:: one wave per pair (throughput), awvw:: four waves per pair
+#define AWV_NS awv
+#define AWV_WG 64
 #include "biwfa_device.hpp"
+#undef AWV_NS
+#undef AWV_WG
+#define AWV_NS awvw
+#define AWV_WG 256
+#include "biwfa_device.hpp"
+#undef AWV_NS
+#undef AWV_WG
 
 #include <algorithm>
 #include <chrono>
@@ -316,17 +326,33 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
         amap.swap(order);
       }
     }
-    const int wcap_full = ((maxsum + 9 + 256 + 2 * COL_PAD) + 255) & ~255;
-    const int nslots_want = (int)std::min<int64_t>(nslots_cfg, n);
+    if (int rc = e->d_pair_q.reserve((size_t)n)) return rc;
+    if (int rc = e->d_pair_t.reserve((size_t)n)) return rc;
+    if (int rc = e->d_pair_rc.reserve((size_t)n)) return rc;
+    if (int rc = e->d_cigar_off.reserve((size_t)n)) return rc;
+    if (int rc = e->d_results.reserve((size_t)n)) return rc;
+    if (int rc = e->d_cigar.reserve((size_t)arena + 64)) return rc;
+    if (int rc = e->d_counters.reserve(1 + STAT_N)) return rc;
+    static_assert(sizeof(awv_result) == sizeof(DevResult), "result layout");
+    hres.assign((size_t)n, awv_result{});
+    // One group of the batch = one kernel flavour: `wide` pairs get a 256-thread workgroup each (four
+    // waves deal a row's windows among themselves), the others one wave each.
+    auto run_group = [&](std::vector<int32_t> hq, std::vector<int32_t> ht, std::vector<int32_t> hrc, std::vector<uint64_t> hoff,
+                         std::vector<int64_t> amap, bool wide, int g_maxsum, int g_maxlen) -> int {
+    if (hq.empty()) return AWV_OK;
+    const int wg = wide ? 256 : 64;
+    const int nslots_g = e->cfg.workgroups > 0 ? std::max(1, e->cfg.workgroups / (wg / 64)) : (WAVES_PER_SIMD * 256 / wg) * e->num_cus;
+    const int wcap_full = ((g_maxsum + 9 + 256 + 2 * COL_PAD) + 255) & ~255;
+    const int nslots_want = (int)std::min<int64_t>(nslots_g, (int64_t)hq.size());
     // 16-bit wavefront rows whenever every offset fits (halves the HBM/L2 traffic of the rings)
-    const bool narrow = maxlen < 32760 && !(e->cfg.flags & AWV_F_FORCE_INT32);
+    const bool narrow = g_maxlen < 32760 && !(e->cfg.flags & AWV_F_FORCE_INT32);
     const size_t esz = narrow ? 2 : 4;
     // dynamic LDS = ring metadata (16-bit entries with 16-bit rows) + staging of the 2-bit packed
     // sequences: what the largest pair needs, within 160 KB / (16 waves per CU) per workgroup;
     // sub-problems that do not fit read global memory instead
     const size_t lds_meta = lds_meta_bytes(narrow ? sizeof(RowMeta16) : sizeof(RowMeta));
-    const size_t seq_need = ((((size_t)maxlen + 15) / 16 + 2) * 2 + 10) * 4;
-    const size_t lds_budget = (size_t)(160 * 1024 / (WAVES_PER_SIMD * 256 / WG)) - STATIC_LDS_RESERVE;
+    const size_t seq_need = ((((size_t)g_maxlen + 15) / 16 + 2) * 2 + 10) * 4;
+    const size_t lds_budget = (size_t)(160 * 1024 / (WAVES_PER_SIMD * 256 / wg)) - STATIC_LDS_RESERVE;
     size_t lds_seq = (e->cfg.flags & AWV_F_NO_PACKED_SEQ) ? 0 : (lds_meta < lds_budget ? std::min(seq_need, lds_budget - lds_meta) : 0);
     lds_seq &= ~(size_t)15;
     const size_t dyn_lds = lds_meta + lds_seq;
@@ -345,7 +371,10 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     // Half-width rows (at least 8192 columns) already hold every pair whose optimal score is below
     // about a quarter of plen + tlen; they halve the arenas (allocating -- and the driver clearing --
     // tens of GB is the largest fixed cost of a call) and only unusually divergent pairs are re-run.
-    int wcap = std::min(wcap_full, std::max(8192, (wcap_full / 2 + 255) & ~255));
+    // (a length difference forces a gap that long: the rows must span it in both directions)
+    int g_maxdelta = 0;
+    for (size_t i = 0; i < hq.size(); ++i) g_maxdelta = std::max(g_maxdelta, std::abs(s.len[hq[i]] - s.len[ht[i]]));
+    int wcap = std::min(wcap_full, std::max(std::max(8192, (wcap_full / 2 + 255) & ~255), (2 * g_maxdelta + 4096 + 255) & ~255));
     if (per_slot(wcap) * (size_t)nslots_want > budget) {
       const size_t fixed = hist_stride + 2 * (size_t)2 * ring * sizeof(int);
       const size_t per_col = (size_t)2 * NCOMP * ring * esz + sizeof(uint32_t) + (size_t)2 * ring * sizeof(int) / 256 + 1;
@@ -355,15 +384,6 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       wcap = (int)std::min<long long>(wcap, wc);
     }
     if (const char* env = getenv("AWV_WCAP_MAX")) wcap = std::min(wcap, std::max(2048, atoi(env)));  // experiment knob
-    if (int rc = e->d_pair_q.reserve((size_t)n)) return rc;
-    if (int rc = e->d_pair_t.reserve((size_t)n)) return rc;
-    if (int rc = e->d_pair_rc.reserve((size_t)n)) return rc;
-    if (int rc = e->d_cigar_off.reserve((size_t)n)) return rc;
-    if (int rc = e->d_results.reserve((size_t)n)) return rc;
-    if (int rc = e->d_cigar.reserve((size_t)arena + 64)) return rc;
-    if (int rc = e->d_counters.reserve(1 + STAT_N)) return rc;
-    static_assert(sizeof(awv_result) == sizeof(DevResult), "result layout");
-    hres.assign((size_t)n, awv_result{});
     // ---- attempts: the whole batch at row capacity `wcap`, then only the pairs that outgrew it
     std::vector<awv_result> tres;
     float ms = 0;
@@ -373,7 +393,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       const size_t ev_stride = (size_t)wc + EV_EXTRA;  // run-length events + the DFS stack
       const int chunks_cap = wc / 256 + 2;
       const size_t chunk_stride = (size_t)2 * ring * chunks_cap;
-      int nslots = (int)std::min<int64_t>(nslots_cfg, m);
+      int nslots = (int)std::min<int64_t>(nslots_g, m);
       {  // keep the per-workgroup arenas inside the scratch budget (default 160 GiB of the 288 GB HBM)
         const size_t fit = std::max<size_t>(1, budget / per_slot(wc));
         if ((size_t)nslots > fit) nslots = (int)fit;
@@ -430,14 +450,22 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       kp.work_counter = e->d_counters.p;
       kp.stats = e->d_counters.p + 1;
       HIP_TRY(hipEventRecord(e->ev0, e->stream));
-      auto launch = [&](auto kern) -> int {
+      auto launch = [&](auto kern, const auto& kparams) -> int {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
-        hipLaunchKernelGGL(kern, dim3(nslots), dim3(WG), dyn_lds, e->stream, kp);
+        hipLaunchKernelGGL(kern, dim3(nslots), dim3(wg), dyn_lds, e->stream, kparams);
         return AWV_OK;
       };
       int lrc;
-      if (dp.two_piece) lrc = narrow ? launch(biwfa_align_kernel<true, int16_t>) : launch(biwfa_align_kernel<true, int32_t>);
-      else lrc = narrow ? launch(biwfa_align_kernel<false, int16_t>) : launch(biwfa_align_kernel<false, int32_t>);
+      if (!wide) {
+        if (dp.two_piece) lrc = narrow ? launch(awv::biwfa_align_kernel<true, int16_t>, kp) : launch(awv::biwfa_align_kernel<true, int32_t>, kp);
+        else lrc = narrow ? launch(awv::biwfa_align_kernel<false, int16_t>, kp) : launch(awv::biwfa_align_kernel<false, int32_t>, kp);
+      } else {
+        static_assert(sizeof(awvw::KParams) == sizeof(awv::KParams), "same parameter block for both workgroup sizes");
+        awvw::KParams kw;
+        std::memcpy(&kw, &kp, sizeof(kw));
+        if (dp.two_piece) lrc = narrow ? launch(awvw::biwfa_align_kernel<true, int16_t>, kw) : launch(awvw::biwfa_align_kernel<true, int32_t>, kw);
+        else lrc = narrow ? launch(awvw::biwfa_align_kernel<false, int16_t>, kw) : launch(awvw::biwfa_align_kernel<false, int32_t>, kw);
+      }
       if (lrc != AWV_OK) return lrc;
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(e->ev1, e->stream));
@@ -478,6 +506,28 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       hq.swap(q2); ht.swap(t2); hrc.swap(rc2); hoff.swap(off2); amap.swap(map2);
       wc = (int)std::min<long long>(wcap_full, 4LL * wc);
     }
+    return AWV_OK;
+    };
+    {
+      // which pairs go wide: all of a small batch (latency), all pairs of long sequences (their rows are
+      // tens of windows wide; measured +17 % on 100 kbp pairs), and pairs a length difference makes expensive
+      const bool never_wide = (e->cfg.flags & AWV_F_ONE_WAVE) != 0;
+      const bool all_wide = !never_wide && ((e->cfg.flags & AWV_F_FOUR_WAVES) || n <= (int64_t)(WAVES_PER_SIMD * e->num_cus) || maxlen >= 32760);
+      std::vector<int32_t> q[2], t[2], rc[2];
+      std::vector<uint64_t> off[2];
+      std::vector<int64_t> map[2];
+      int gsum[2] = {0, 0}, glen[2] = {0, 0};
+      for (int64_t i = 0; i < n; ++i) {
+        const int ql = s.len[hq[(size_t)i]], tl = s.len[ht[(size_t)i]];
+        const int g = (all_wide || (!never_wide && std::abs(ql - tl) >= 4096)) ? 1 : 0;
+        q[g].push_back(hq[(size_t)i]); t[g].push_back(ht[(size_t)i]); rc[g].push_back(hrc[(size_t)i]); off[g].push_back(hoff[(size_t)i]);
+        map[g].push_back(amap.empty() ? i : amap[(size_t)i]);
+        gsum[g] = std::max(gsum[g], ql + tl);
+        glen[g] = std::max(glen[g], std::max(ql, tl));
+      }
+      if (int rc1 = run_group(std::move(q[1]), std::move(t[1]), std::move(rc[1]), std::move(off[1]), std::move(map[1]), true, gsum[1], glen[1])) return rc1;
+      if (int rc0 = run_group(std::move(q[0]), std::move(t[0]), std::move(rc[0]), std::move(off[0]), std::move(map[0]), false, gsum[0], glen[0])) return rc0;
+    }
     const bool want_cigar = sink && !(e->cfg.flags & AWV_F_KEEP_ON_DEVICE);
     lap("results on host");
     if (want_cigar) {
@@ -487,8 +537,9 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       HIP_TRY(hipMemcpyAsync(e->h_cigar.data(), e->d_cigar.p, (size_t)arena, hipMemcpyDeviceToHost, e->stream));
       HIP_TRY(hipEventRecord(e->ev1, e->stream));
       HIP_TRY(hipEventSynchronize(e->ev1));
-      HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-      d2h_ms += ms;
+      float ms_c = 0;
+      HIP_TRY(hipEventElapsedTime(&ms_c, e->ev0, e->ev1));
+      d2h_ms += ms_c;
     }
     lap("cigars on host");
     if (out) std::memcpy(out + first, hres.data(), (size_t)n * sizeof(awv_result));

@@ -28,9 +28,12 @@ def hip_lib():
     return ffi.load()
 
 
-@pytest.fixture(scope="session")
-def engine(hip_lib):
+@pytest.fixture(scope="session", params=["auto", "one_wave"])
+def engine(hip_lib, request):
+    """The GPU engine, twice: with its own choice of kernel flavour per batch (small batches, long
+    sequences and very unequal pairs get four waves per pair) and pinned to the one-wave-per-pair
+    throughput kernel that bench.py measures."""
     from allwave_amd import ffi
-    e = ffi.Engine(device=0)
+    e = ffi.Engine(device=0, flags=ffi.AWV_F_ONE_WAVE if request.param == "one_wave" else 0)
     yield e
     e.close()

@@ -178,8 +178,9 @@ def test_bad_arguments(engine):
 
 
 def test_row_width_and_sequence_paths_agree(oracle):
-    """The kernel variants must be interchangeable: 16-bit vs forced 32-bit wavefront rows, 2-bit
-    packed LDS staging vs raw-byte probes from HBM -- all bit-exact against the oracle."""
+    """The kernel variants must be interchangeable: one wave vs four waves per pair, 16-bit vs forced
+    32-bit wavefront rows, 2-bit packed LDS staging vs raw-byte probes from HBM -- all bit-exact
+    against the oracle."""
     from allwave_amd import ffi
     rng = random.Random(4242)
     seqs, pairs = [], []
@@ -187,7 +188,9 @@ def test_row_width_and_sequence_paths_agree(oracle):
         s, t = random_pair(rng, 2500)
         seqs += [s, t]
         pairs.append((len(seqs) - 2, len(seqs) - 1))
-    for flags in (0, ffi.AWV_F_FORCE_INT32, ffi.AWV_F_NO_PACKED_SEQ, ffi.AWV_F_FORCE_INT32 | ffi.AWV_F_NO_PACKED_SEQ):
+    for flags in (ffi.AWV_F_ONE_WAVE, ffi.AWV_F_FOUR_WAVES, ffi.AWV_F_ONE_WAVE | ffi.AWV_F_FORCE_INT32,
+                  ffi.AWV_F_FOUR_WAVES | ffi.AWV_F_FORCE_INT32, ffi.AWV_F_ONE_WAVE | ffi.AWV_F_NO_PACKED_SEQ,
+                  ffi.AWV_F_FOUR_WAVES | ffi.AWV_F_NO_PACKED_SEQ, ffi.AWV_F_ONE_WAVE | ffi.AWV_F_FORCE_INT32 | ffi.AWV_F_NO_PACKED_SEQ):
         e = ffi.Engine(flags=flags)
         try:
             for scores in (DEFAULT_2P, (0, 4, 6, 2)):
