@@ -5,7 +5,8 @@
 // wavefront arenas sized for 288 GB of HBM, result/CIGAR arenas, one stream.  There is no CPU
 // fallback: without a HIP device every entry point fails with AWV_ERR_NO_DEVICE.
 #include "allwave_hip.h"
-// the device code, once per workgroup size: awv:: one wave per pair (throughput), awvw:: four waves per pair
+// the device code, once per workgroup size: awv:: one wave per pair (throughput), awvw:: four waves per pair,
+// awvx:: sixteen waves per pair (one pair per CU: the few pairs a large length difference makes enormous)
 #define AWV_NS awv
 #define AWV_WG 64
 #include "biwfa_device.hpp"
@@ -13,6 +14,11 @@
 #undef AWV_WG
 #define AWV_NS awvw
 #define AWV_WG 256
+#include "biwfa_device.hpp"
+#undef AWV_NS
+#undef AWV_WG
+#define AWV_NS awvx
+#define AWV_WG 1024
 #include "biwfa_device.hpp"
 #undef AWV_NS
 #undef AWV_WG
@@ -338,9 +344,9 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     // One group of the batch = one kernel flavour: `wide` pairs get a 256-thread workgroup each (four
     // waves deal a row's windows among themselves), the others one wave each.
     auto run_group = [&](std::vector<int32_t> hq, std::vector<int32_t> ht, std::vector<int32_t> hrc, std::vector<uint64_t> hoff,
-                         std::vector<int64_t> amap, bool wide, int g_maxsum, int g_maxlen) -> int {
+                         std::vector<int64_t> amap, int waves, int g_maxsum, int g_maxlen) -> int {
     if (hq.empty()) return AWV_OK;
-    const int wg = wide ? 256 : 64;
+    const int wg = 64 * waves;
     const int nslots_g = e->cfg.workgroups > 0 ? std::max(1, e->cfg.workgroups / (wg / 64)) : (WAVES_PER_SIMD * 256 / wg) * e->num_cus;
     const int wcap_full = ((g_maxsum + 9 + 256 + 2 * COL_PAD) + 255) & ~255;
     const int nslots_want = (int)std::min<int64_t>(nslots_g, (int64_t)hq.size());
@@ -456,15 +462,21 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
         return AWV_OK;
       };
       int lrc;
-      if (!wide) {
+      static_assert(sizeof(awvw::KParams) == sizeof(awv::KParams) && sizeof(awvx::KParams) == sizeof(awv::KParams),
+                    "same parameter block for every workgroup size");
+      if (waves == 1) {
         if (dp.two_piece) lrc = narrow ? launch(awv::biwfa_align_kernel<true, int16_t>, kp) : launch(awv::biwfa_align_kernel<true, int32_t>, kp);
         else lrc = narrow ? launch(awv::biwfa_align_kernel<false, int16_t>, kp) : launch(awv::biwfa_align_kernel<false, int32_t>, kp);
-      } else {
-        static_assert(sizeof(awvw::KParams) == sizeof(awv::KParams), "same parameter block for both workgroup sizes");
+      } else if (waves == 4) {
         awvw::KParams kw;
         std::memcpy(&kw, &kp, sizeof(kw));
         if (dp.two_piece) lrc = narrow ? launch(awvw::biwfa_align_kernel<true, int16_t>, kw) : launch(awvw::biwfa_align_kernel<true, int32_t>, kw);
         else lrc = narrow ? launch(awvw::biwfa_align_kernel<false, int16_t>, kw) : launch(awvw::biwfa_align_kernel<false, int32_t>, kw);
+      } else {
+        awvx::KParams kx;
+        std::memcpy(&kx, &kp, sizeof(kx));
+        if (dp.two_piece) lrc = narrow ? launch(awvx::biwfa_align_kernel<true, int16_t>, kx) : launch(awvx::biwfa_align_kernel<true, int32_t>, kx);
+        else lrc = narrow ? launch(awvx::biwfa_align_kernel<false, int16_t>, kx) : launch(awvx::biwfa_align_kernel<false, int32_t>, kx);
       }
       if (lrc != AWV_OK) return lrc;
       HIP_TRY(hipGetLastError());
@@ -513,20 +525,27 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       // tens of windows wide; measured +17 % on 100 kbp pairs), and pairs a length difference makes expensive
       const bool never_wide = (e->cfg.flags & AWV_F_ONE_WAVE) != 0;
       const bool all_wide = !never_wide && ((e->cfg.flags & AWV_F_FOUR_WAVES) || n <= (int64_t)(WAVES_PER_SIMD * e->num_cus) || maxlen >= 32760);
-      std::vector<int32_t> q[2], t[2], rc[2];
-      std::vector<uint64_t> off[2];
-      std::vector<int64_t> map[2];
-      int gsum[2] = {0, 0}, glen[2] = {0, 0};
+      std::vector<int32_t> q[3], t[3], rc[3];
+      std::vector<uint64_t> off[3];
+      std::vector<int64_t> map[3];
+      int gsum[3] = {0, 0, 0}, glen[3] = {0, 0, 0};
+      // sixteen waves per pair only pay while such pairs are too few to fill the machine four waves at a time
+      int64_t n_huge = 0;
+      for (int64_t i = 0; i < n; ++i) n_huge += std::abs(s.len[hq[(size_t)i]] - s.len[ht[(size_t)i]]) >= 16384;
+      const bool use_sixteen = !never_wide && !(e->cfg.flags & AWV_F_FOUR_WAVES) && n_huge > 0 && n_huge <= (int64_t)e->num_cus;
       for (int64_t i = 0; i < n; ++i) {
         const int ql = s.len[hq[(size_t)i]], tl = s.len[ht[(size_t)i]];
-        const int g = (all_wide || (!never_wide && std::abs(ql - tl) >= 4096)) ? 1 : 0;
+        const int dl = std::abs(ql - tl);
+        int g = (all_wide || (!never_wide && dl >= 4096)) ? 1 : 0;
+        if (use_sixteen && dl >= 16384) g = 2;  // a forced gap that long: rows hundreds of windows wide
         q[g].push_back(hq[(size_t)i]); t[g].push_back(ht[(size_t)i]); rc[g].push_back(hrc[(size_t)i]); off[g].push_back(hoff[(size_t)i]);
         map[g].push_back(amap.empty() ? i : amap[(size_t)i]);
         gsum[g] = std::max(gsum[g], ql + tl);
         glen[g] = std::max(glen[g], std::max(ql, tl));
       }
-      if (int rc1 = run_group(std::move(q[1]), std::move(t[1]), std::move(rc[1]), std::move(off[1]), std::move(map[1]), true, gsum[1], glen[1])) return rc1;
-      if (int rc0 = run_group(std::move(q[0]), std::move(t[0]), std::move(rc[0]), std::move(off[0]), std::move(map[0]), false, gsum[0], glen[0])) return rc0;
+      static const int waves_of[3] = {1, 4, 16};
+      for (int g = 2; g >= 0; --g)
+        if (int rcg = run_group(std::move(q[g]), std::move(t[g]), std::move(rc[g]), std::move(off[g]), std::move(map[g]), waves_of[g], gsum[g], glen[g])) return rcg;
     }
     const bool want_cigar = sink && !(e->cfg.flags & AWV_F_KEEP_ON_DEVICE);
     lap("results on host");

@@ -308,3 +308,22 @@ def test_row_width_boundary(engine, oracle, length):
     b = mutate(a, 0.03, rng)[:length]
     b = b + rand_seq(rng, length - len(b))
     check_against_oracle(engine, oracle, [a, b], [(0, 1), (1, 0)], DEFAULT_2P)
+
+
+def test_very_unequal_lengths(oracle):
+    """A length difference forces a gap that long: |dlen| >= 4096 routes a pair to the four-wave
+    flavour, >= 16384 to the sixteen-wave one (one pair per CU); both bit-exact, and identical to
+    the one-wave kernel's answer."""
+    from allwave_amd import ffi
+    rng = random.Random(31337)
+    a = rand_seq(rng, 19000)
+    b = mutate(a, 0.04, rng)[7000:8500]      # 1.5 kbp infix: dlen = 17.5 k
+    c = mutate(a, 0.04, rng)[:13000]         # 13 kbp prefix: dlen = 6 k
+    seqs = [a, b, c]
+    pairs = [(1, 0), (0, 1), (2, 0), (0, 2)]
+    for flags in (0, ffi.AWV_F_ONE_WAVE):
+        e = ffi.Engine(flags=flags)
+        try:
+            check_against_oracle(e, oracle, seqs, pairs, DEFAULT_2P)
+        finally:
+            e.close()
