@@ -344,7 +344,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     // One group of the batch = one kernel flavour: `wide` pairs get a 256-thread workgroup each (four
     // waves deal a row's windows among themselves), the others one wave each.
     auto run_group = [&](std::vector<int32_t> hq, std::vector<int32_t> ht, std::vector<int32_t> hrc, std::vector<uint64_t> hoff,
-                         std::vector<int64_t> amap, int waves, int g_maxsum, int g_maxlen) -> int {
+                         std::vector<int64_t> amap, int waves, int g_maxsum, int g_maxlen, bool reserve_only) -> int {
     if (hq.empty()) return AWV_OK;
     const int wg = 64 * waves;
     const int nslots_g = e->cfg.workgroups > 0 ? std::max(1, e->cfg.workgroups / (wg / 64)) : (WAVES_PER_SIMD * 256 / wg) * e->num_cus;
@@ -408,6 +408,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       if (int rc = e->hist_mem.reserve(hist_stride * nslots)) return rc;
       if (int rc = e->ev_mem.reserve(ev_stride * nslots)) return rc;
       if (int rc = e->chunk_mem.reserve(chunk_stride * nslots)) return rc;
+      if (reserve_only) return AWV_OK;  // (first pass over the groups: one allocation covers them all)
       lap("arenas reserved");
       // ---- H2D
       HIP_TRY(hipEventRecord(e->ev0, e->stream));
@@ -544,8 +545,26 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
         glen[g] = std::max(glen[g], std::max(ql, tl));
       }
       static const int waves_of[3] = {1, 4, 16};
+      // the arenas are sized for the most demanding group first: growing them between two groups would
+      // mean a free followed by a large allocation, which the driver can take seconds over
+      {  // (reserve in descending order of estimated ring demand; DevBuf::reserve only ever grows)
+        std::pair<size_t, int> demand[3];
+        for (int g = 0; g < 3; ++g) {
+          demand[g] = {0, g};
+          if (q[g].empty()) continue;
+          const int wgx = 64 * waves_of[g];
+          const int64_t slots = std::min<int64_t>((WAVES_PER_SIMD * 256 / wgx) * e->num_cus, (int64_t)q[g].size());
+          demand[g].first = (size_t)slots * (size_t)gsum[g] * (glen[g] < 32760 ? 2 : 4);
+        }
+        std::sort(demand, demand + 3, [](const std::pair<size_t, int>& a, const std::pair<size_t, int>& b) { return a.first > b.first; });
+        for (int k = 0; k < 3; ++k) {
+          const int g = demand[k].second;
+          if (q[g].empty()) continue;
+          if (int rcg = run_group(q[g], t[g], rc[g], off[g], map[g], waves_of[g], gsum[g], glen[g], true)) return rcg;
+        }
+      }
       for (int g = 2; g >= 0; --g)
-        if (int rcg = run_group(std::move(q[g]), std::move(t[g]), std::move(rc[g]), std::move(off[g]), std::move(map[g]), waves_of[g], gsum[g], glen[g])) return rcg;
+        if (int rcg = run_group(std::move(q[g]), std::move(t[g]), std::move(rc[g]), std::move(off[g]), std::move(map[g]), waves_of[g], gsum[g], glen[g], false)) return rcg;
     }
     const bool want_cigar = sink && !(e->cfg.flags & AWV_F_KEEP_ON_DEVICE);
     lap("results on host");
