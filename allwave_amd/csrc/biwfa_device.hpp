@@ -1159,7 +1159,6 @@ template <bool P2, typename OffT>
 __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& lds, const SubCtx& cx, void* ring_mem, rsrc_t ring_rs, int d0, int s0,
                                 int s1, bool fwd, Breakpoint& bp, unsigned long long* lstats) {
   constexpr int VEC = OffTraits<OffT>::VEC;
-  constexpr int WSPAN = 64 * VEC;
   const DevPenalties& pn = kp.pen;
   const int d1 = 1 - d0;
   const int tid = cold_tid(), lane = tid & 63, wave = tid >> 6;

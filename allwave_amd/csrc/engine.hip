@@ -256,7 +256,6 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   }
   int ring = 4;
   while (ring < dp.scope + 2) ring *= 2;
-  const int nslots_cfg = e->cfg.workgroups > 0 ? e->cfg.workgroups : (WAVES_PER_SIMD * 256 / WG) * e->num_cus;
   const int64_t max_batch = e->cfg.max_batch_pairs > 0 ? e->cfg.max_batch_pairs : (int64_t)1 << 20;
   const uint64_t max_arena = e->cfg.max_arena_bytes > 0 ? (uint64_t)e->cfg.max_arena_bytes : (uint64_t)8 << 30;
   // base-case capacities: score_remaining <= 250 or both lengths <= 100
