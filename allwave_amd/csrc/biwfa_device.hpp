@@ -111,9 +111,6 @@ struct KParams {
   size_t hist_meta_offset;  // byte offset of the base-case metadata log inside a hist slot
   uint32_t* ev_mem;
   size_t ev_slot_stride;
-  int* chunk_mem;            // per workgroup: [2 dirs][ring][chunks_cap] max antidiagonal of each 256-column chunk of the M row
-  size_t chunk_slot_stride;  // ints per workgroup
-  int chunks_cap;
   uint8_t* cigar;
   const uint64_t* cigar_off;
   DevResult* results;
@@ -158,7 +155,6 @@ struct Lds {
   int* firstk;
   uint32_t* seq;   // sequence staging (2-bit packed words, or raw bytes)
   RowMeta* meta_log;  // HBM: [score][NCOMP] of the running base case
-  int* chunk_ak;      // HBM: [dir][ring slot][chunk] max antidiagonal per 256-column chunk (overlap filter)
 };
 struct Shared {
   Acc acc[3][2];
@@ -548,7 +544,7 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
   constexpr int VEC = OffTraits<OffT>::VEC;
   static_assert(VEC == 4, "lane vectors are 4 diagonals wide");
   constexpr int WSPAN = 64 * VEC;
-  static_assert(WSPAN == 256, "window = 256 columns (64 lane vectors), chunk = 256 columns");
+  static_assert(WSPAN == 256, "window = 256 columns (64 lane vectors)");
   constexpr int PROD = 62;                // productive lanes 1..62
   constexpr int WSTRIDE = PROD * VEC;     // 248 new columns per window
   constexpr int ESZ = (int)sizeof(OffT);
@@ -579,10 +575,6 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
   const int colLo = lo - kmin, colHi = hi - kmin;
   int lane_maxak = 0;
   bool lane_oob = false;
-  // The overlap filter keeps the M row's antidiagonal maxima per absolute 256-column chunk; a window
-  // touches at most two chunks, and a chunk's maximum is carried until the walk leaves the chunk.
-  int* const ck = BASE ? nullptr : lds.chunk_ak + ((size_t)dir * kp.ring + (score & (kp.ring - 1))) * kp.chunks_cap;
-  int cur_chunk = -1, cur_max = 0;
   const bool productive = lane >= 1 && lane <= PROD;
   // Windows that need no masking at all, as a range of window origins [int_lo, int_hi], found once
   // per row.  With trimmed rows around (`dirty`): the productive columns and their +-1 halo lie
@@ -831,35 +823,13 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
       if (m[j] >= 0) it_maxak = max(it_maxak, 2 * m[j] - (k0 + j));
-    if (!BASE && NWAVES == 1) {  // chunk maxima for the overlap filter (several waves per pair: no chunk filter)
-      const int first_col = cb + VEC;                                // column of lane 1
-      const int chunk_lo = first_col >> 8;
-      const int nlow = (((chunk_lo + 1) << 8) - first_col) / VEC;    // productive lanes 1..nlow lie in chunk_lo
-      if (chunk_lo != cur_chunk) {
-        if (cur_chunk >= 0 && lane == 0) ck[cur_chunk] = cur_max;
-        cur_chunk = chunk_lo;
-        cur_max = 0;
-      }
-      if (nlow >= PROD) {
-        cur_max = max(cur_max, wave_max_i32(it_maxak));
-      } else {
-        cur_max = max(cur_max, wave_max_i32(lane <= nlow ? it_maxak : 0));
-        lane_maxak = max(lane_maxak, cur_max);
-        if (lane == 0) ck[cur_chunk] = cur_max;
-        cur_chunk = chunk_lo + 1;
-        cur_max = wave_max_i32(lane <= nlow ? 0 : it_maxak);
-      }
-      lane_maxak = max(lane_maxak, cur_max);  // (row maximum = max over the chunk maxima seen)
-    } else {
-      lane_maxak = max(lane_maxak, it_maxak);
-    }
+    lane_maxak = max(lane_maxak, it_maxak);
     if (lane_on) buf_store_vec<OffT>(rs, voff, tM, m, tlen);
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_STORE, tc3);
   }
   const unsigned long long tc4 = PROF_NOW();
-  if (!BASE && NWAVES == 1 && cur_chunk >= 0 && lane == 0) ck[cur_chunk] = cur_max;  // the last chunk of the walk
-  const int wmax = (BASE || NWAVES > 1) ? wave_max_i32(lane_maxak) : lane_maxak;  // (already wave-uniform per window otherwise)
+  const int wmax = wave_max_i32(lane_maxak);  // one reduction per row: the row's max antidiagonal
   const bool woob = __any(lane_oob);
   if (lane == 0) {
     atomicMax(&acc.maxak, wmax);
@@ -1194,32 +1164,14 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
   if (!any) return;
   for (int i = tid; i < pn.scope * NCOMP; i += WG) lds.firstk[i] = INT_MAX;
   __syncthreads();
-  // stage 1: parallel scan of every candidate wavefront pair (superset of what the sequential
-  // search visits: the best score only decreases within a call).  Per score pair a chunk mask is
-  // built first: chunk c of side 0 faces chunk (Cm-255)/256 - c of side 1, and only chunk pairs whose
-  // M-row antidiagonal maxima reach plen + tlen can hold an overlap (same bound as the row filter).
+  // stage 1: parallel scan of every candidate wavefront pair that passes the row filter (superset of
+  // what the sequential search visits: the best score only decreases within a call), 256 columns
+  // (one chunk) at a time: chunk c of side 0 faces the mirrored chunk of side 1.
   constexpr int ESZ = (int)sizeof(OffT);
-  const int mirror_chunk = (Cm - 255) >> 8;
-  const int* ck0 = lds.chunk_ak + ((size_t)d0 * kp.ring + slot0) * kp.chunks_cap;
-  auto chunk_mask = [&](int si) -> uint64_t {
-    if (WG > 64) return ~0ull;  // several waves per pair keep no chunk maxima: the M-row gate prunes instead
-    if (oob0 || uni(lds.bi_oob[(d1) * kp.ring + (si & rmask)])) return ~0ull;
-    const RowMeta m0 = uni(meta_load(&lds.ring_meta[(d0 * NCOMP + C_M) * kp.ring + slot0]));
-    const RowMeta m1 = uni(meta_load(&lds.ring_meta[(d1 * NCOMP + C_M) * kp.ring + (si & rmask)]));
-    if (row_empty(m0) || row_empty(m1)) return 0ull;
-    const int* ck1 = lds.chunk_ak + ((size_t)d1 * kp.ring + (si & rmask)) * kp.chunks_cap;
-    const int c0lo = (m0.lo - kmin0) >> 8, c0hi = (m0.hi - kmin0) >> 8;
-    const int c1lo = (m1.lo - kmin1) >> 8, c1hi = (m1.hi - kmin1) >> 8;
-    if (c0hi >= 64) return ~0ull;  // very wide rows: no chunk filter
-    const int j = lane, j1 = mirror_chunk - lane;
-    bool ok = false;
-    if (j >= c0lo && j <= c0hi && j1 >= c1lo && j1 <= c1hi) ok = ck0[j] + ck1[j1] >= L;
-    return __ballot(ok);
-  };
   // All components of one score pair are scanned together: per candidate chunk the rows of every
   // wanted component are loaded back to back (one memory round trip), then compared in turn.
   // Per component the first hit in ascending k wins, as in the sequential search.
-  auto scan_all = [&](int i, int si, uint64_t cmask, unsigned want) {
+  auto scan_all = [&](int i, int si, unsigned want) {
     int ca[NCOMP], cbn[NCOMP], so0[NCOMP], so1[NCOMP];
     unsigned live = 0;
     int chlo = INT_MAX, chhi = -1;
@@ -1250,7 +1202,6 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
     const int so0M = row_off<false, OffT>(kp, d0, C_M, s0), so1M = row_off<false, OffT>(kp, d1, C_M, si);
     int nth = 0;  // waves take the candidate chunks round-robin, each in ascending order
     for (int ch = chlo; ch <= chhi && live; ++ch) {
-      if (ch < 64 && !((cmask >> ch) & 1ull)) continue;  // (chunks >= 64 are not filtered)
       unsigned here = 0;
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c)
@@ -1314,9 +1265,7 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
       const int si = s1 - i;
       const bool w2 = P2 && s0 + si - pn.o2 < bp.score, w1 = s0 + si - pn.o1 < bp.score, w0 = s0 + si < bp.score;
       if (!(w2 || w1 || w0)) continue;
-      const uint64_t cmask = chunk_mask(si);
-      if (cmask == 0) continue;
-      scan_all(i, si, cmask, (w2 ? (1u << C_D2) | (1u << C_I2) : 0u) | (w1 ? (1u << C_D1) | (1u << C_I1) : 0u) | (w0 ? 1u << C_M : 0u));
+      scan_all(i, si, (w2 ? (1u << C_D2) | (1u << C_I2) : 0u) | (w1 ? (1u << C_D1) | (1u << C_I1) : 0u) | (w0 ? 1u << C_M : 0u));
     }
   }
   __syncthreads();
@@ -1370,7 +1319,7 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
     const int adj = ((255 - c0) % 256 + 256) % 256;  // mirror on whole 256-column chunks
     cx.kmin[1] = need - adj;
     cx.wcols = blo + bhi + 9 + adj + 2 * COL_PAD;
-    if (cx.wcols > kp.wcap || (cx.wcols >> 8) + 1 > kp.chunks_cap) return ST_CAPACITY;
+    if (cx.wcols > kp.wcap) return ST_CAPACITY;
   }
   // score-0 wavefronts (wavefront_unialign_init by begin component)
   for (int i = tid; i < 2 * NCOMP; i += WG) {
@@ -1391,7 +1340,6 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
       row[col] = (OffT)v0;
     }
     sh.ext0[dir] = v0;
-    lds.chunk_ak[((size_t)dir * kp.ring + 0) * kp.chunks_cap + ((0 - (dir ? cx.kmin[1] : cx.kmin[0])) >> 8)] = (begin == C_M) ? 2 * v0 : 0;
     lds.bi_A[(dir) * kp.ring + (0)] = (begin == C_M) ? 2 * v0 : 0;
     lds.bi_oob[(dir) * kp.ring + (0)] = 0;
     acc_reset(sh.acc[0][dir]);
@@ -1522,7 +1470,6 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
   const rsrc_t ring_rs = make_rsrc(ring_mem, kp.ring_slot_stride);
   const rsrc_t hist_rs = make_rsrc(hist, kp.hist_slot_stride);
   lds.meta_log = reinterpret_cast<RowMeta*>((char*)hist + kp.hist_meta_offset);
-  lds.chunk_ak = kp.chunk_mem + (size_t)blockIdx.x * kp.chunk_slot_stride;
   if (tid < STAT_N) lstats[tid] = 0;
   if (tid < 5) sh.prof[tid] = 0;
   __syncthreads();

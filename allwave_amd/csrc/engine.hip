@@ -124,7 +124,6 @@ struct awv_engine {
   // scratch arenas (per persistent workgroup)
   DevBuf<uint8_t> ring_mem, hist_mem;
   DevBuf<uint32_t> ev_mem;
-  DevBuf<int> chunk_mem;
   // per-launch buffers
   DevBuf<int32_t> d_pair_q, d_pair_t, d_pair_rc;
   DevBuf<uint64_t> d_cigar_off;
@@ -366,8 +365,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     // per-workgroup arenas as a function of the row capacity (columns)
     const size_t budget = e->cfg.max_scratch_bytes > 0 ? (size_t)e->cfg.max_scratch_bytes : (size_t)160 << 30;
     auto per_slot = [&](int wc) {
-      return (size_t)2 * NCOMP * ring * wc * esz + hist_stride + (size_t)(wc + EV_EXTRA) * sizeof(uint32_t) +
-             (size_t)2 * ring * (wc / 256 + 2) * sizeof(int);
+      return (size_t)2 * NCOMP * ring * wc * esz + hist_stride + (size_t)(wc + EV_EXTRA) * sizeof(uint32_t);
     };
     // Row capacity of the first attempt.  A wavefront at score s spans at most ~2 s / min(e) diagonals,
     // far fewer than plen + tlen for similar sequences; when full-width rows would not leave room for
@@ -381,8 +379,8 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     for (size_t i = 0; i < hq.size(); ++i) g_maxdelta = std::max(g_maxdelta, std::abs(s.len[hq[i]] - s.len[ht[i]]));
     int wcap = std::min(wcap_full, std::max(std::max(8192, (wcap_full / 2 + 255) & ~255), (2 * g_maxdelta + 4096 + 255) & ~255));
     if (per_slot(wcap) * (size_t)nslots_want > budget) {
-      const size_t fixed = hist_stride + 2 * (size_t)2 * ring * sizeof(int);
-      const size_t per_col = (size_t)2 * NCOMP * ring * esz + sizeof(uint32_t) + (size_t)2 * ring * sizeof(int) / 256 + 1;
+      const size_t fixed = hist_stride + EV_EXTRA * sizeof(uint32_t);
+      const size_t per_col = (size_t)2 * NCOMP * ring * esz + sizeof(uint32_t);
       const size_t share = budget / (size_t)nslots_want;
       long long wc = share > fixed ? (long long)((share - fixed) / per_col) : 0;
       wc = std::max<long long>(wc & ~255LL, 8192);
@@ -396,8 +394,6 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       const int64_t m = (int64_t)hq.size();
       const size_t ring_stride = (size_t)2 * NCOMP * ring * wc * esz;
       const size_t ev_stride = (size_t)wc + EV_EXTRA;  // run-length events + the DFS stack
-      const int chunks_cap = wc / 256 + 2;
-      const size_t chunk_stride = (size_t)2 * ring * chunks_cap;
       int nslots = (int)std::min<int64_t>(nslots_g, m);
       {  // keep the per-workgroup arenas inside the scratch budget (default 160 GiB of the 288 GB HBM)
         const size_t fit = std::max<size_t>(1, budget / per_slot(wc));
@@ -406,7 +402,6 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       if (int rc = e->ring_mem.reserve(ring_stride * nslots)) return rc;
       if (int rc = e->hist_mem.reserve(hist_stride * nslots)) return rc;
       if (int rc = e->ev_mem.reserve(ev_stride * nslots)) return rc;
-      if (int rc = e->chunk_mem.reserve(chunk_stride * nslots)) return rc;
       if (reserve_only) return AWV_OK;  // (first pass over the groups: one allocation covers them all)
       lap("arenas reserved");
       // ---- H2D
@@ -447,9 +442,6 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       kp.hist_meta_offset = hist_rows;
       kp.ev_mem = e->ev_mem.p;
       kp.ev_slot_stride = ev_stride;
-      kp.chunk_mem = e->chunk_mem.p;
-      kp.chunk_slot_stride = chunk_stride;
-      kp.chunks_cap = chunks_cap;
       kp.cigar = e->d_cigar.p;
       kp.cigar_off = e->d_cigar_off.p;
       kp.results = e->d_results.p;
@@ -598,7 +590,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   e->stats.overlap_scans = stat_tot[STAT_OVERLAP];
   e->stats.aligned_bp = stat_tot[STAT_ALIGNED_BP];
   e->stats.pairs_completed = stat_tot[STAT_PAIRS];
-  e->stats.scratch_bytes = e->ring_mem.bytes() + e->hist_mem.bytes() + e->ev_mem.bytes() + e->chunk_mem.bytes();
+  e->stats.scratch_bytes = e->ring_mem.bytes() + e->hist_mem.bytes() + e->ev_mem.bytes();
   for (int i = 0; i < 14; ++i) e->stats.prof[i] = stat_tot[STAT_T_TOTAL + i];
   return AWV_OK;
 }
@@ -650,7 +642,6 @@ void awv_engine_destroy(awv_engine* e) {
   e->ring_mem.release();
   e->hist_mem.release();
   e->ev_mem.release();
-  e->chunk_mem.release();
   e->d_pair_q.release();
   e->d_pair_t.release();
   e->d_pair_rc.release();
