@@ -1200,8 +1200,42 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
     // values around: their M cells are stored as NULL while the I/D cells keep the value.)
     const bool m_gate = !oob0 && !uni(lds.bi_oob[d1 * kp.ring + (si & rmask)]);
     const int so0M = row_off<false, OffT>(kp, d0, C_M, s0), so1M = row_off<false, OffT>(kp, d1, C_M, si);
+    // One wave per pair: the gate loads of up to four chunks are in flight together (a candidate's
+    // range is a few chunks and nearly all of them fail the gate), so a candidate costs one memory
+    // round trip instead of one per chunk.
+    const bool pregated = m_gate && WG == 64 && chhi - chlo < 64;
+    uint64_t gate_pass = ~0ull;  // bit (ch - chlo): the chunk passed the gate
+    if (pregated) {
+      gate_pass = 0;
+      for (int cg = chlo; cg <= chhi; cg += 4) {
+        RawVec<OffT> g0[4], g1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          g0[u] = RawVec<OffT>{};
+          g1[u] = RawVec<OffT>{};
+          if (cg + u <= chhi) {
+            const int c0 = ((cg + u) << 8) + lane * VEC;
+            g0[u] = buf_load_raw<OffT>(ring_rs, c0 * ESZ, so0M);
+            g1[u] = buf_load_raw<OffT>(ring_rs, (Cm - c0 - (VEC - 1)) * ESZ, so1M);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (cg + u > chhi) continue;
+          int32_t a0[VEC], a1[VEC];
+          unpack_raw<OffT>(g0[u], a0);
+          unpack_raw<OffT>(g1[u], a1);
+          bool reach = false;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) reach = reach || (a0[j] >= 0 && a1[VEC - 1 - j] >= 0 && a0[j] + a1[VEC - 1 - j] >= tlen);
+          if (__ballot(reach) != 0) gate_pass |= 1ull << (cg + u - chlo);
+        }
+      }
+      if (gate_pass == 0) return;
+    }
     int nth = 0;  // waves take the candidate chunks round-robin, each in ascending order
     for (int ch = chlo; ch <= chhi && live; ++ch) {
+      if (pregated && !((gate_pass >> (ch - chlo)) & 1ull)) continue;
       unsigned here = 0;
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c)
@@ -1211,7 +1245,7 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
       if (tid == 0) lstats[STAT_OVERLAP] += (unsigned long long)__builtin_popcount(here);
       const int cbase = ch << 8;
       const int c0 = cbase + lane * VEC;
-      if (m_gate) {
+      if (m_gate && !pregated) {
         int32_t g0[VEC], g1[VEC];
         unpack_raw<OffT>(buf_load_raw<OffT>(ring_rs, c0 * ESZ, so0M), g0);
         unpack_raw<OffT>(buf_load_raw<OffT>(ring_rs, (Cm - c0 - (VEC - 1)) * ESZ, so1M), g1);
