@@ -125,10 +125,6 @@ struct Acc { int hull_lo[NCOMP]; int hull_hi[NCOMP]; int maxak; int oob; };
 struct Task { int pb, pe, tb, te, cb, ce, score_remaining; };
 struct Breakpoint { int score, sf, sr, kf, kr, off_f, off_r, comp; };
 
-// LDS: a small static part plus one dynamic region carved per launch (sizes depend on the
-// penalties' ring depth, the base-case score capacity and the sequence staging budget):
-//   [ bi_meta[2][NCOMP][ring] | bi_A[2][ring] | bi_oob[2][ring] | firstk[scope*NCOMP] ]  (BiWFA search)
-//   [ seq: the sub-problem's pattern and text bytes, 8-byte padded ]
 struct RowMeta16 { int16_t lo, hi; };  // |k| < 32760 whenever 16-bit rows are in use; empty = {1, 0}
 template <typename OffT> struct MetaTraits;
 template <> struct MetaTraits<int16_t> { typedef RowMeta16 Stored; };
@@ -153,7 +149,7 @@ struct Lds {
   int* bi_A;
   int* bi_oob;
   int* firstk;
-  uint32_t* seq;   // sequence staging (2-bit packed words, or raw bytes)
+  uint32_t* seq;   // sequence staging: the sub-problem's 2-bit packed words (16 bases per word)
   RowMeta* meta_log;  // HBM: [score][NCOMP] of the running base case
 };
 struct Shared {
