@@ -308,6 +308,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     // estimated here from the lengths and the gap a length difference forces).  Results and CIGARs
     // keep their caller-order slots through the index map.  Equal-cost batches keep caller order.
     std::vector<int64_t> amap;  // dispatch index -> batch index (empty = identity)
+    bool skewed = false;  // the most expensive pair costs several times the median one
     {
       std::vector<int64_t> order((size_t)n);
       std::vector<uint64_t> cost((size_t)n);
@@ -327,6 +328,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
           q2[(size_t)i] = hq[o]; t2[(size_t)i] = ht[o]; rc2[(size_t)i] = hrc[o]; off2[(size_t)i] = hoff[o];
         }
         hq.swap(q2); ht.swap(t2); hrc.swap(rc2); hoff.swap(off2);
+        skewed = cost[(size_t)order[0]] >= 3 * cost[(size_t)order[(size_t)n / 2]];
         amap.swap(order);
       }
     }
@@ -516,7 +518,9 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       // which pairs go wide: all of a small batch (latency), all pairs of long sequences (their rows are
       // tens of windows wide; measured +17 % on 100 kbp pairs), and pairs a length difference makes expensive
       const bool never_wide = (e->cfg.flags & AWV_F_ONE_WAVE) != 0;
-      const bool all_wide = !never_wide && ((e->cfg.flags & AWV_F_FOUR_WAVES) || n <= (int64_t)(WAVES_PER_SIMD * e->num_cus) || maxlen >= 32760);
+      // (a batch of uneven pairs that fits the machine about once is bound by its longest pairs, not by throughput)
+      const bool all_wide = !never_wide && ((e->cfg.flags & AWV_F_FOUR_WAVES) || n <= (int64_t)(WAVES_PER_SIMD * e->num_cus) || maxlen >= 32760 ||
+                                            (skewed && n <= (int64_t)(4 * WAVES_PER_SIMD * e->num_cus)));
       std::vector<int32_t> q[3], t[3], rc[3];
       std::vector<uint64_t> off[3];
       std::vector<int64_t> map[3];

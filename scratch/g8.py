@@ -11,7 +11,7 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 maxlen = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
 rng = random.Random(seed)
-e = ffi.Engine()
+e = ffi.Engine(flags=int(os.environ.get("G8_FLAGS", "0")))
 bad = total = 0
 sets = PENALTY_SETS + [(0, 6, 10, 3, 70, 2), (0, 1, 1, 1)]
 for scores in sets:
