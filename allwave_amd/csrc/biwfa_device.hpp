@@ -1391,6 +1391,13 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
   int rc = BP_OK;
   const int gap_opening = P2 ? max(pn.o1, pn.o2) : pn.o1;
   bool last_fwd = false;
+  // A sub-problem handed down by a parent's breakpoint with match components at both ends has a known
+  // optimal score: its share of the parent's optimal alignment, `score_remaining` (both boundaries
+  // are in M, so the child's accounting charges every gap open exactly as the parent's did, and a
+  // cheaper way to its end would make the parent's alignment cheaper too).  WFA2 keeps searching until
+  // no better overlap is possible but only ever replaces the breakpoint by a strictly better one, so
+  // once that score is reached the rest of the search cannot change the result and is skipped.
+  const bool known_optimum = cb == C_M && ce == C_M && score_remaining != INT_MAX;
   bool dirty[2] = {false, false};  // per direction: some row was trimmed, later steps mask element by element
   int phase = 1;
   // One loop for both phases (A.6).  Each iteration first makes sure the next forward and the next
@@ -1453,6 +1460,7 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
         const unsigned long long to0 = PROF_NOW();
         bialign_overlap<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, 0, sc[0], sc[1], true, bp, lstats);
         PROF_ADD(STAT_T_OVERLAP, to0);
+        if (known_optimum && bp.score == score_remaining) break;
         ++sc[1];
       }
       const int min_sf = (sc[0] > pn.scope - 1) ? sc[0] - (pn.scope - 1) : 0;
@@ -1460,6 +1468,7 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
       const unsigned long long to1 = PROF_NOW();
       bialign_overlap<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, 1, sc[1], sc[0], false, bp, lstats);
       PROF_ADD(STAT_T_OVERLAP, to1);
+      if (known_optimum && bp.score == score_remaining) break;
       ++sc[0];
       last_fwd = true;
     }
