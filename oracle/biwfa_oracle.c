@@ -957,7 +957,11 @@ static void bialign_overlap(wf_aligner_t* a0, wf_aligner_t* a1, int score_0, int
 
 /* WFA2: wavefront_bialign_find_breakpoint (A.6).  Returns WF_STATUS_OK with *bp set,
  * WF_STATUS_END_REACHED if one direction finished alone at score 0, or an error. */
-static int bialign_find_breakpoint(awo_aligner_t* A, int cb, int ce, bialign_breakpoint_t* bp) {
+/* score_remaining: the share of the parent's optimal alignment this sub-problem was handed (INT_MAX at
+ * the top level).  Only the CPU-baseline mode looks at it: with match components at both ends it IS the
+ * sub-problem's optimal score, WFA2 only ever replaces the breakpoint by a strictly better one, so the
+ * search may stop as soon as that score is reached -- same result (tests/test_oracle.py checks it). */
+static int bialign_find_breakpoint(awo_aligner_t* A, int cb, int ce, int score_remaining, bialign_breakpoint_t* bp) {
   wf_aligner_t* f = &A->fwd;
   wf_aligner_t* r = &A->rev;
   f->stats = r->stats = A->stats;
@@ -991,11 +995,13 @@ static int bialign_find_breakpoint(awo_aligner_t* A, int cb, int ce, bialign_bre
   /* phase 2: advance until no better overlap is possible */
   const int max_score_scope = f->max_score_scope;
   const int gap_opening = f->two_piece ? MAXI(f->o1, f->o2) : f->o1;
+  const bool known_optimum = f->fast_overlap && cb == COMP_M && ce == COMP_M && score_remaining != INT_MAX;
   while (true) {
     if (last_wf_forward) {
       const int min_score_reverse = (score_reverse > max_score_scope - 1) ? score_reverse - (max_score_scope - 1) : 0;
       if (score_forward + min_score_reverse - gap_opening >= bp->score) break;
       bialign_overlap(f, r, score_forward, score_reverse, true, bp);
+      if (known_optimum && bp->score == score_remaining) break;
       ++score_reverse;
       if (!wf_compute(r, score_reverse)) return WF_STATUS_ERROR;
       wf_extend_end2end(r, score_reverse, NULL);
@@ -1003,6 +1009,7 @@ static int bialign_find_breakpoint(awo_aligner_t* A, int cb, int ce, bialign_bre
     const int min_score_forward = (score_forward > max_score_scope - 1) ? score_forward - (max_score_scope - 1) : 0;
     if (min_score_forward + score_reverse - gap_opening >= bp->score) break;
     bialign_overlap(r, f, score_reverse, score_forward, false, bp);
+    if (known_optimum && bp->score == score_remaining) break;
     ++score_forward;
     if (!wf_compute(f, score_forward)) return WF_STATUS_ERROR;
     wf_extend_end2end(f, score_forward, NULL);
@@ -1036,7 +1043,7 @@ static int bialign_alignment(awo_aligner_t* A, int pb, int pe, int tb, int te, i
   /* fall back to regular WFA */
   if (score_remaining <= WF_BIALIGN_FALLBACK_MIN_SCORE) return bialign_base(A, cb, ce, penalty);
   bialign_breakpoint_t bp;
-  const int st = bialign_find_breakpoint(A, cb, ce, &bp);
+  const int st = bialign_find_breakpoint(A, cb, ce, score_remaining, &bp);
   if (st == WF_STATUS_END_REACHED) return bialign_base(A, cb, ce, penalty); /* wavefront_bialign_exception */
   if (st != WF_STATUS_OK || bp.score == INT_MAX) return AWO_ERR_INTERNAL;
   const int bh = WF_H(bp.k_forward, bp.offset_forward);

@@ -158,12 +158,21 @@ def test_all_pairs_driver(oracle):
 
 
 def test_fast_overlap_mode_is_identical(oracle):
-    """The CPU-baseline mode (exact antidiagonal pre-filter in the overlap search) must return the
-    same penalties and CIGARs as the plain WFA2-order search the checker uses."""
+    """The CPU-baseline mode (exact antidiagonal pre-filter in the overlap search; a sub-problem with
+    match components at both ends stops searching at its known optimal score -- the two exact
+    shortcuts the GPU kernel also takes) must return the same penalties and CIGARs as the plain
+    WFA2-order search the checker uses, also on pairs with long gaps (breakpoints inside gaps)."""
     rng = random.Random(77)
-    for scores in (DEFAULT_2P, EDIT, (0, 3, 5, 1, 20, 1)):
+    for scores in (DEFAULT_2P, EDIT, (0, 3, 5, 1, 20, 1), (0, 2, 12, 1, 40, 1)):
         plain, fast = oracle.Aligner(scores), oracle.Aligner(scores)
         fast.set_fast_overlap(True)
-        for _ in range(60):
-            s, t = random_pair(rng, 3000)
+        for it in range(70):
+            s, t = random_pair(rng, 4000)
+            if it % 3 == 0:  # cut long gaps out of the text
+                for _ in range(rng.randint(1, 3)):
+                    cut = rng.randint(0, len(t))
+                    t = t[:cut] + t[min(len(t), cut + rng.randint(20, 900)):]
+            elif it % 3 == 1:  # or insert unrelated sequence
+                cut = rng.randint(0, len(t))
+                t = t[:cut] + rand_seq(rng, rng.randint(20, 600)) + t[cut:]
             assert plain.align(s, t) == fast.align(s, t)
