@@ -441,24 +441,37 @@ __device__ __forceinline__ void hull_add(RowMeta& h, const RowMeta& s, int dlo, 
 template <bool P2, bool BASE, typename OffT>
 __device__ __forceinline__ void plan_step(const KParams& kp, const Lds<OffT>& lds, int dir, int score, StepPlan& pl) {
   const DevPenalties& pn = kp.pen;
-  pl.src[0] = get_meta<OffT>(kp, lds, dir, C_M, score - pn.x);
-  pl.src[1] = get_meta<OffT>(kp, lds, dir, C_M, score - pn.o1 - pn.e1);
-  pl.src[2] = get_meta<OffT>(kp, lds, dir, C_I1, score - pn.e1);
-  pl.src[3] = get_meta<OffT>(kp, lds, dir, C_D1, score - pn.e1);
-  pl.src[4] = pl.src[5] = pl.src[6] = ROW_EMPTY;
-  if (P2) {
-    pl.src[4] = get_meta<OffT>(kp, lds, dir, C_M, score - pn.o2 - pn.e2);
-    pl.src[5] = get_meta<OffT>(kp, lds, dir, C_I2, score - pn.e2);
-    pl.src[6] = get_meta<OffT>(kp, lds, dir, C_D2, score - pn.e2);
+  // The nine metadata entries are fetched by nine lanes in one LDS round trip and handed out with
+  // readlane: lanes 0..6 the sources (Mx, O1, I1e, D1e, O2, I2e, D2e), lanes 7 / 8 the M rows of the
+  // I/D sources' scores (their steps' hulls).
+  {
+    const int lane = threadIdx.x & 63;
+    const int lag = lane == 0 ? pn.x : lane == 1 ? pn.o1 + pn.e1 : (lane == 2 || lane == 3 || lane == 7) ? pn.e1 : lane == 4 ? pn.o2 + pn.e2 : pn.e2;
+    const int comp = lane == 2 ? C_I1 : lane == 3 ? C_D1 : lane == 5 ? C_I2 : lane == 6 ? C_D2 : C_M;
+    const int sc_l = score - lag;
+    RowMeta mine = ROW_EMPTY;
+    if (lane < 9 && sc_l >= 0 && (P2 || (lane != 4 && lane != 5 && lane != 6 && lane != 8)))
+      mine = meta_load(&lds.ring_meta[(dir * NCOMP + comp) * kp.ring + (sc_l & (kp.ring - 1))]);
+    auto hand = [&](int l) { return RowMeta{__builtin_amdgcn_readlane(mine.lo, l), __builtin_amdgcn_readlane(mine.hi, l)}; };
+    pl.src[0] = hand(0);
+    pl.src[1] = hand(1);
+    pl.src[2] = hand(2);
+    pl.src[3] = hand(3);
+    pl.src[4] = pl.src[5] = pl.src[6] = ROW_EMPTY;
+    if (P2) {
+      pl.src[4] = hand(4);
+      pl.src[5] = hand(5);
+      pl.src[6] = hand(6);
+    }
+    // Every step stores whole lane vectors over its hull for all components (cells outside a
+    // component's own range hold NULL), so while no row has been trimmed a source row can be masked
+    // by whole lane vectors against the hull of the step that wrote it.
+    pl.hull[0] = pl.src[0];
+    pl.hull[1] = pl.src[1];
+    pl.hull[2] = pl.hull[3] = hand(7);
+    pl.hull[4] = pl.src[4];
+    pl.hull[5] = pl.hull[6] = P2 ? hand(8) : ROW_EMPTY;
   }
-  // Every step stores whole lane vectors over its hull for all components (cells outside a
-  // component's own range hold NULL), so while no row has been trimmed a source row can be masked
-  // by whole lane vectors against the hull of the step that wrote it.
-  pl.hull[0] = pl.src[0];
-  pl.hull[1] = pl.src[1];
-  pl.hull[2] = pl.hull[3] = get_meta<OffT>(kp, lds, dir, C_M, score - pn.e1);
-  pl.hull[4] = pl.src[4];
-  pl.hull[5] = pl.hull[6] = P2 ? get_meta<OffT>(kp, lds, dir, C_M, score - pn.e2) : ROW_EMPTY;
   // (the score-0 row of a sub-problem that begins in an indel component has that cell and no M cell)
   if (score - pn.e1 == 0) { pl.hull[2] = pl.src[2]; pl.hull[3] = pl.src[3]; }
   if (P2 && score - pn.e2 == 0) { pl.hull[5] = pl.src[5]; pl.hull[6] = pl.src[6]; }
