@@ -122,7 +122,7 @@ struct RowMeta { int lo, hi; };
 constexpr int K_BIG = 1 << 28;  // an empty row is {K_BIG, -K_BIG}: min/max hulls ignore it for free
 #define ROW_EMPTY RowMeta{K_BIG, -K_BIG}
 struct Acc { int hull_lo[NCOMP]; int hull_hi[NCOMP]; int maxak; int oob; };
-struct Task { int pb, pe, tb, te, cb, ce, score_remaining; };
+struct Task { int pb, pe, tb, te, cb, ce, score_remaining, known; };  // known: the sub-problem's optimal score (INT_MAX at the top)
 struct Breakpoint { int score, sf, sr, kf, kr, off_f, off_r, comp; };
 
 struct RowMeta16 { int16_t lo, hi; };  // |k| < 32760 whenever 16-bit rows are in use; empty = {1, 0}
@@ -1342,7 +1342,7 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
 
 template <bool P2, typename OffT>
 __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& lds, SubCtx cx, void* ring_mem, rsrc_t ring_rs, int cb, int ce,
-                               int score_remaining, Breakpoint& bp, unsigned long long* lstats) {
+                               int score_remaining, int known_score, Breakpoint& bp, unsigned long long* lstats) {
   const DevPenalties& pn = kp.pen;
   const int tid = cold_tid();
   const int plen = cx.plen, tlen = cx.tlen;
@@ -1404,13 +1404,14 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
   int rc = BP_OK;
   const int gap_opening = P2 ? max(pn.o1, pn.o2) : pn.o1;
   bool last_fwd = false;
-  // A sub-problem handed down by a parent's breakpoint with match components at both ends has a known
-  // optimal score: its share of the parent's optimal alignment, `score_remaining` (both boundaries
-  // are in M, so the child's accounting charges every gap open exactly as the parent's did, and a
-  // cheaper way to its end would make the parent's alignment cheaper too).  WFA2 keeps searching until
-  // no better overlap is possible but only ever replaces the breakpoint by a strictly better one, so
-  // once that score is reached the rest of the search cannot change the result and is skipped.
-  const bool known_optimum = cb == C_M && ce == C_M && score_remaining != INT_MAX;
+  // A sub-problem handed down by a parent's breakpoint has a known optimal score: its share of the
+  // parent's optimal alignment (the forward / reverse score at the breakpoint) minus the gap open of
+  // the breakpoint's component -- in the child that boundary gap is pre-paid at its begin or end, while
+  // both of the parent's searches had paid for entering it.  A cheaper way through the child would make
+  // the parent's alignment cheaper too.  WFA2 keeps searching until no better overlap is possible but
+  // only ever replaces the breakpoint by a strictly better one, so once that score is reached the rest
+  // of the search cannot change the result and is skipped.
+  const bool known_optimum = known_score != INT_MAX;
   bool dirty[2] = {false, false};  // per direction: some row was trimmed, later steps mask element by element
   int phase = 1;
   // One loop for both phases (A.6).  Each iteration first makes sure the next forward and the next
@@ -1473,7 +1474,7 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
         const unsigned long long to0 = PROF_NOW();
         bialign_overlap<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, 0, sc[0], sc[1], true, bp, lstats);
         PROF_ADD(STAT_T_OVERLAP, to0);
-        if (known_optimum && bp.score == score_remaining) break;
+        if (known_optimum && bp.score == known_score) break;
         ++sc[1];
       }
       const int min_sf = (sc[0] > pn.scope - 1) ? sc[0] - (pn.scope - 1) : 0;
@@ -1481,7 +1482,7 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
       const unsigned long long to1 = PROF_NOW();
       bialign_overlap<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, 1, sc[1], sc[0], false, bp, lstats);
       PROF_ADD(STAT_T_OVERLAP, to1);
-      if (known_optimum && bp.score == score_remaining) break;
+      if (known_optimum && bp.score == known_score) break;
       ++sc[0];
       last_fwd = true;
     }
@@ -1558,7 +1559,7 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
     int sp = 0;
     if (tid == 0) {
       const bool min_length = max(plenT, tlenT) <= FALLBACK_MIN_LENGTH;
-      stack[0] = Task{0, plenT, 0, tlenT, C_M, C_M, min_length ? 0 : INT_MAX};
+      stack[0] = Task{0, plenT, 0, tlenT, C_M, C_M, min_length ? 0 : INT_MAX, INT_MAX};
     }
     sp = 1;
     __syncthreads();
@@ -1566,7 +1567,7 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
     while (sp > 0 && status == ST_OK) {
       Task t = stack[sp - 1];
       t.pb = uni(t.pb); t.pe = uni(t.pe); t.tb = uni(t.tb); t.te = uni(t.te);
-      t.cb = uni(t.cb); t.ce = uni(t.ce); t.score_remaining = uni(t.score_remaining);
+      t.cb = uni(t.cb); t.ce = uni(t.ce); t.score_remaining = uni(t.score_remaining); t.known = uni(t.known);
       --sp;
       __syncthreads();  // everyone has read the entry before it can be overwritten
       const int plen = t.pe - t.pb, tlen = t.te - t.tb;
@@ -1598,7 +1599,7 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
       bool do_base = t.score_remaining <= FALLBACK_MIN_SCORE;
       Breakpoint bp;
       if (!do_base) {
-        const int rc = find_breakpoint<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, t.cb, t.ce, t.score_remaining, bp, lstats);
+        const int rc = find_breakpoint<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, t.cb, t.ce, t.score_remaining, t.known, bp, lstats);
         if (rc == BP_END_REACHED) do_base = true;  // wavefront_bialign_exception -> plain WFA
         else if (rc != BP_OK) { status = rc; break; }
       }
@@ -1613,8 +1614,9 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
       const int bh = bp.off_f, bv = bp.off_f - bp.kf;
       if (bh < 0 || bh > tlen || bv < 0 || bv > plen || sp + 2 > STACK_CAP) { status = ST_INTERNAL; break; }
       if (tid == 0) {
-        stack[sp] = Task{t.pb + bv, t.pe, t.tb + bh, t.te, bp.comp, t.ce, bp.sr};      // right half
-        stack[sp + 1] = Task{t.pb, t.pb + bv, t.tb, t.tb + bh, t.cb, bp.comp, bp.sf};  // left half first
+        const int open_c = bp.comp == C_M ? 0 : ((bp.comp == C_I1 || bp.comp == C_D1) ? kp.pen.o1 : kp.pen.o2);
+        stack[sp] = Task{t.pb + bv, t.pe, t.tb + bh, t.te, bp.comp, t.ce, bp.sr, bp.sr - open_c};      // right half
+        stack[sp + 1] = Task{t.pb, t.pb + bv, t.tb, t.tb + bh, t.cb, bp.comp, bp.sf, bp.sf - open_c};  // left half first
       }
       sp += 2;
       if (top) penalty = bp.score;

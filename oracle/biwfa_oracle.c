@@ -957,11 +957,12 @@ static void bialign_overlap(wf_aligner_t* a0, wf_aligner_t* a1, int score_0, int
 
 /* WFA2: wavefront_bialign_find_breakpoint (A.6).  Returns WF_STATUS_OK with *bp set,
  * WF_STATUS_END_REACHED if one direction finished alone at score 0, or an error. */
-/* score_remaining: the share of the parent's optimal alignment this sub-problem was handed (INT_MAX at
- * the top level).  Only the CPU-baseline mode looks at it: with match components at both ends it IS the
- * sub-problem's optimal score, WFA2 only ever replaces the breakpoint by a strictly better one, so the
- * search may stop as soon as that score is reached -- same result (tests/test_oracle.py checks it). */
-static int bialign_find_breakpoint(awo_aligner_t* A, int cb, int ce, int score_remaining, bialign_breakpoint_t* bp) {
+/* known_score: the sub-problem's optimal score when a parent's breakpoint handed it down -- its share
+ * (forward / reverse score at that breakpoint) minus the gap open of the breakpoint's component, which
+ * the child has pre-paid at its begin or end; INT_MAX at the top level.  Only the CPU-baseline mode looks
+ * at it: WFA2 only ever replaces the breakpoint by a strictly better one, so the search may stop as soon
+ * as that score is reached -- same result (tests/test_oracle.py checks it against the plain search). */
+static int bialign_find_breakpoint(awo_aligner_t* A, int cb, int ce, int known_score, bialign_breakpoint_t* bp) {
   wf_aligner_t* f = &A->fwd;
   wf_aligner_t* r = &A->rev;
   f->stats = r->stats = A->stats;
@@ -995,13 +996,13 @@ static int bialign_find_breakpoint(awo_aligner_t* A, int cb, int ce, int score_r
   /* phase 2: advance until no better overlap is possible */
   const int max_score_scope = f->max_score_scope;
   const int gap_opening = f->two_piece ? MAXI(f->o1, f->o2) : f->o1;
-  const bool known_optimum = f->fast_overlap && cb == COMP_M && ce == COMP_M && score_remaining != INT_MAX;
+  const bool known_optimum = f->fast_overlap && known_score != INT_MAX;
   while (true) {
     if (last_wf_forward) {
       const int min_score_reverse = (score_reverse > max_score_scope - 1) ? score_reverse - (max_score_scope - 1) : 0;
       if (score_forward + min_score_reverse - gap_opening >= bp->score) break;
       bialign_overlap(f, r, score_forward, score_reverse, true, bp);
-      if (known_optimum && bp->score == score_remaining) break;
+      if (known_optimum && bp->score == known_score) break;
       ++score_reverse;
       if (!wf_compute(r, score_reverse)) return WF_STATUS_ERROR;
       wf_extend_end2end(r, score_reverse, NULL);
@@ -1009,7 +1010,7 @@ static int bialign_find_breakpoint(awo_aligner_t* A, int cb, int ce, int score_r
     const int min_score_forward = (score_forward > max_score_scope - 1) ? score_forward - (max_score_scope - 1) : 0;
     if (min_score_forward + score_reverse - gap_opening >= bp->score) break;
     bialign_overlap(r, f, score_reverse, score_forward, false, bp);
-    if (known_optimum && bp->score == score_remaining) break;
+    if (known_optimum && bp->score == known_score) break;
     ++score_forward;
     if (!wf_compute(f, score_forward)) return WF_STATUS_ERROR;
     wf_extend_end2end(f, score_forward, NULL);
@@ -1023,7 +1024,7 @@ static int bialign_find_breakpoint(awo_aligner_t* A, int cb, int ce, int score_r
 
 /* WFA2: wavefront_bialign_alignment (A.6 recursion) */
 static int bialign_alignment(awo_aligner_t* A, int pb, int pe, int tb, int te, int cb, int ce,
-                             int score_remaining, int level, int* penalty) {
+                             int score_remaining, int known_score, int level, int* penalty) {
   const int plen = pe - pb, tlen = te - tb;
   if (A->stats && (uint32_t)level > A->stats->max_level) A->stats->max_level = (uint32_t)level;
   /* trivial cases */
@@ -1043,15 +1044,17 @@ static int bialign_alignment(awo_aligner_t* A, int pb, int pe, int tb, int te, i
   /* fall back to regular WFA */
   if (score_remaining <= WF_BIALIGN_FALLBACK_MIN_SCORE) return bialign_base(A, cb, ce, penalty);
   bialign_breakpoint_t bp;
-  const int st = bialign_find_breakpoint(A, cb, ce, score_remaining, &bp);
+  const int st = bialign_find_breakpoint(A, cb, ce, known_score, &bp);
   if (st == WF_STATUS_END_REACHED) return bialign_base(A, cb, ce, penalty); /* wavefront_bialign_exception */
   if (st != WF_STATUS_OK || bp.score == INT_MAX) return AWO_ERR_INTERNAL;
   const int bh = WF_H(bp.k_forward, bp.offset_forward);
   const int bv = WF_V(bp.k_forward, bp.offset_forward);
   if (bh < 0 || bh > tlen || bv < 0 || bv > plen) return AWO_ERR_INTERNAL;
-  int rc = bialign_alignment(A, pb, pb + bv, tb, tb + bh, cb, bp.component, bp.score_forward, level + 1, NULL);
+  const int open_c = bp.component == COMP_M ? 0
+                     : ((bp.component == COMP_I1 || bp.component == COMP_D1) ? A->pen.gap_open1 : A->pen.gap_open2);
+  int rc = bialign_alignment(A, pb, pb + bv, tb, tb + bh, cb, bp.component, bp.score_forward, bp.score_forward - open_c, level + 1, NULL);
   if (rc != AWO_OK) return rc;
-  rc = bialign_alignment(A, pb + bv, pe, tb + bh, te, bp.component, ce, bp.score_reverse, level + 1, NULL);
+  rc = bialign_alignment(A, pb + bv, pe, tb + bh, te, bp.component, ce, bp.score_reverse, bp.score_reverse - open_c, level + 1, NULL);
   if (rc != AWO_OK) return rc;
   if (penalty) *penalty = bp.score;
   return AWO_OK;
@@ -1111,7 +1114,7 @@ int awo_align(awo_aligner_t* A, const uint8_t* pattern, int plen, const uint8_t*
   /* WFA2: wavefront_bialign -- short sequences fall back to plain WFA (score_remaining = 0) */
   const bool min_length = MAXI(plen, tlen) <= WF_BIALIGN_FALLBACK_MIN_LENGTH;
   int pen = -1;
-  rc = bialign_alignment(A, 0, plen, 0, tlen, COMP_M, COMP_M, min_length ? 0 : INT_MAX, 0, &pen);
+  rc = bialign_alignment(A, 0, plen, 0, tlen, COMP_M, COMP_M, min_length ? 0 : INT_MAX, INT_MAX, 0, &pen);
   if (rc != AWO_OK) return rc;
   if (pen < 0) { /* trivial top-level problem: one all-gap run */
     const int n = plen + tlen;
