@@ -76,6 +76,11 @@ struct DevBuf {
     p = nullptr;
     cap = 0;
   }
+  void adopt(T* q, size_t n) {
+    release();
+    p = q;
+    cap = n;
+  }
   size_t bytes() const { return cap * sizeof(T); }
 };
 
@@ -228,6 +233,45 @@ int check_penalties(const awv_penalties* p, awv::DevPenalties& d) {
   d.scope = scope + 1;
   if (d.scope + 2 > awv::MAX_RING) return fail(AWV_ERR_PENALTIES, "penalties too large: max(x, o+e) must be < 126");
   return AWV_OK;
+}
+
+// ---- arena placement --------------------------------------------------------------------------
+// Where a multi-GB arena lands in HBM is worth up to +-6 % of the row traffic's rate (measured: the
+// same kernel on five arenas allocated one after the other ran 1315..1465 ms, each arena keeping its
+// rate; scratch/src/memplace.hip shows the same split with nothing but the traffic).  So the ring
+// arena is chosen: a few candidates are allocated, each is timed with a few milliseconds of the step
+// kernel's traffic pattern (rows 1, 2, 5, 10 and 25 steps old read, five rows written, per 248-column
+// window, one wave per workgroup slot), the fastest is kept and the others are freed.
+__global__ __launch_bounds__(64, 4) void arena_probe_kernel(unsigned char* arena, size_t slot_stride, int row_bytes, int steps, int width_cols,
+                                                             unsigned long long* sink) {
+  const int lane = threadIdx.x;
+  awv::rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(arena + (size_t)blockIdx.x * slot_stride, 0, (int)std::min<size_t>(slot_stride, 0x7FFFFFFF), 0x00020000);
+  auto off = [&](int dir, int comp, int score) { return ((dir * 5 + comp) * 32 + (score & 31)) * row_bytes; };
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  unsigned acc = 0;
+  for (int s = 32; s < 32 + steps; ++s) {
+    for (int dir = 0; dir < 2; ++dir) {
+      const int lo = 1024 + (s & 7) * 4;
+      for (int cb = lo; cb < lo + width_cols; cb += 248) {
+        const int voff = (cb + lane * 4) * 2;
+        const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, off(dir, 0, s - 5), 0);
+        const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, off(dir, 0, s - 10), 0);
+        const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, off(dir, 0, s - 25), 0);
+        const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, off(dir, 1, s - 2), 2);
+        const u32x2 f = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, off(dir, 3, s - 2), 2);
+        const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, off(dir, 2, s - 1), 2);
+        const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, off(dir, 4, s - 1), 2);
+        const u32x2 m = a + b + c;
+        acc += m[0] ^ m[1];
+        __builtin_amdgcn_raw_buffer_store_b64(b + d, rs, voff, off(dir, 1, s), 0);
+        __builtin_amdgcn_raw_buffer_store_b64(b + f, rs, voff, off(dir, 3, s), 0);
+        __builtin_amdgcn_raw_buffer_store_b64(c + g, rs, voff, off(dir, 2, s), 0);
+        __builtin_amdgcn_raw_buffer_store_b64(c + h, rs, voff, off(dir, 4, s), 0);
+        __builtin_amdgcn_raw_buffer_store_b64(m, rs, voff, off(dir, 0, s), 0);
+      }
+    }
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
 }
 
 // worst-case penalty of an end-to-end alignment of two sequences of length <= n
@@ -389,6 +433,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       wcap = (int)std::min<long long>(wcap, wc);
     }
     if (const char* env = getenv("AWV_WCAP_MAX")) wcap = std::min(wcap, std::max(2048, atoi(env)));  // experiment knob
+    if (const char* env = getenv("AWV_ROW_PAD")) wcap += atoi(env);  // experiment knob: extra columns per row (row / slot stride phase)
     // ---- attempts: the whole batch at row capacity `wcap`, then only the pairs that outgrew it
     std::vector<awv_result> tres;
     float ms = 0;
@@ -401,11 +446,47 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
         const size_t fit = std::max<size_t>(1, budget / per_slot(wc));
         if ((size_t)nslots > fit) nslots = (int)fit;
       }
-      if (int rc = e->ring_mem.reserve(ring_stride * nslots)) return rc;
+      if (ring_stride * nslots > e->ring_mem.cap) {  // the ring arena grows: choose where it lies (see arena_probe_kernel)
+        const size_t want = ring_stride * (size_t)nslots + ((size_t)64 << 20);
+        size_t free_b = 0, total_b = 0;
+        e->ring_mem.release();
+        (void)hipMemGetInfo(&free_b, &total_b);
+        int ncand = getenv("AWV_NO_ARENA_PROBE") ? 1 : 4;
+        while (ncand > 1 && (size_t)ncand * want > free_b / 10 * 8) --ncand;  // all candidates are alive at once
+        const bool probe_ok = ncand > 1 && want >= ((size_t)1 << 30) && esz == 2 && ring_stride >= (size_t)2 * 5 * 32 * 4096 &&
+                              (size_t)wc * esz >= 4096;
+        if (!probe_ok) ncand = 1;
+        uint8_t* cand[4] = {nullptr, nullptr, nullptr, nullptr};
+        float cms[4] = {0, 0, 0, 0};
+        int best = -1;
+        for (int c = 0; c < ncand; ++c) {
+          if (hipMalloc((void**)&cand[c], want) != hipSuccess) { cand[c] = nullptr; (void)hipGetLastError(); break; }
+          if (ncand == 1) { best = 0; break; }
+          float tbest = 1e30f;
+          for (int rep = 0; rep < 2; ++rep) {
+            HIP_TRY(hipEventRecord(e->ev0, e->stream));
+            hipLaunchKernelGGL(arena_probe_kernel, dim3(nslots), dim3(64), 0, e->stream, cand[c], ring_stride, (int)((size_t)wc * esz), 24,
+                               std::min(1400, wc - 2048), e->d_counters.p);
+            HIP_TRY(hipEventRecord(e->ev1, e->stream));
+            HIP_TRY(hipEventSynchronize(e->ev1));
+            float pms = 0;
+            HIP_TRY(hipEventElapsedTime(&pms, e->ev0, e->ev1));
+            tbest = std::min(tbest, pms);
+          }
+          cms[c] = tbest;
+          if (best < 0 || tbest < cms[best]) best = c;
+          if (timing) fprintf(stderr, "[awv] ring arena candidate %d at %p: %.2f ms\n", c, (void*)cand[c], tbest);
+        }
+        if (best < 0) return fail(AWV_ERR_OOM, "hipMalloc " + std::to_string(want) + " bytes for the ring arena failed");
+        for (int c = 0; c < 4; ++c)
+          if (c != best && cand[c]) (void)hipFree(cand[c]);
+        e->ring_mem.adopt(cand[best], want);
+      }
       if (int rc = e->hist_mem.reserve(hist_stride * nslots)) return rc;
       if (int rc = e->ev_mem.reserve(ev_stride * nslots)) return rc;
       if (reserve_only) return AWV_OK;  // (first pass over the groups: one allocation covers them all)
       lap("arenas reserved");
+      if (timing) fprintf(stderr, "[awv] ring arena %p (%zu MiB), hist %p, cigar %p\n", (void*)e->ring_mem.p, e->ring_mem.bytes() >> 20, (void*)e->hist_mem.p, (void*)e->d_cigar.p);
       // ---- H2D
       HIP_TRY(hipEventRecord(e->ev0, e->stream));
       HIP_TRY(hipMemcpyAsync(e->d_pair_q.p, hq.data(), (size_t)m * 4, hipMemcpyHostToDevice, e->stream));
