@@ -8,8 +8,8 @@ config-2-sized shard of its own (independent pairs, no data-path collective; wea
 value is (bp aligned by all ranks in K steps) / (max over ranks of the timed region).
 
 Sequences are resident in HBM before the timed region.  `roofline` prices the alignment kernel:
-algorithmic bytes (48 B per cell-step for 2-piece, 28 B for 1-piece + extend bytes + CIGAR bytes;
-DESIGN.md) over the kernel's HIP-event duration, against 8 TB/s HBM3E.  `cpu_baseline` is the CPU
+algorithmic bytes (12 row elements per cell-step for 2-piece = 24 B with 16-bit rows / 48 B with 32-bit
+rows, 7 elements for 1-piece, + CIGAR bytes) over the kernel's HIP-event duration, against 8 TB/s HBM3E.  `cpu_baseline` is the CPU
 restatement (oracle/, kind "port") on a bounded sample of the same pairs on this box's host cores.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2] [--pairs P]
@@ -131,7 +131,7 @@ def main():
         except Exception:
             traffic = None
     out = {
-        "metric": "aligned base-pairs/sec (whole node), all-pairs 10 kbp",
+        "metric": "aligned base-pairs/sec (whole node) + PAF lines/sec, all-pairs 10 kbp",
         "value": bp_all / elapsed_max,
         "unit": "bp/s",
         "n_gpus": world,

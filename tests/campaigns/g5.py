@@ -3,7 +3,7 @@ import sys, time, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 from allwave_amd import ffi, synth
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "oracle"))
 import oracle
 
 def run(name, nseq, length, d, seed, mixed, npairs_check, max_pairs=None):
