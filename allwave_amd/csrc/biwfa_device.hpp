@@ -34,6 +34,14 @@
 namespace AWV_NS {
 
 constexpr int WG = AWV_WG;  // threads per workgroup = per sequence pair (64 or 256)
+// Direction split (two waves per pair): in the breakpoint search wave 0 computes the forward rows and
+// wave 1 the reverse rows of a fused pass, each over all of its row's windows.
+#ifdef AWV_DIRSPLIT
+constexpr bool DIRSPLIT = true;
+static_assert(AWV_WG == 128, "direction split = two waves per pair");
+#else
+constexpr bool DIRSPLIT = false;
+#endif
 constexpr int MAX_RING = 128;
 constexpr int NCOMP = 5;
 constexpr int32_t OFF_NULL = INT32_MIN / 2;
@@ -549,7 +557,7 @@ template <bool P2, bool BASE, typename OffT>
 __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const Lds<OffT>& lds, const SubCtx& cx, rsrc_t rs,
                                            int dir, int score, const StepPlan& pl, bool dirty, Acc& acc, unsigned& ext_iters) {
   static_assert(WG % 64 == 0, "whole waves");
-  constexpr int NWAVES = WG / 64;  // a row's windows are dealt round-robin to the workgroup's waves
+  constexpr int NWAVES = (DIRSPLIT && !BASE) ? 1 : WG / 64;  // a row's windows are dealt round-robin to the workgroup's waves (direction split: a row belongs to one wave)
   constexpr int VEC = OffTraits<OffT>::VEC;
   static_assert(VEC == 4, "lane vectors are 4 diagonals wide");
   constexpr int WSPAN = 64 * VEC;
@@ -1212,7 +1220,7 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
     // One wave per pair: the gate loads of up to four chunks are in flight together (a candidate's
     // range is a few chunks and nearly all of them fail the gate), so a candidate costs one memory
     // round trip instead of one per chunk.
-    const bool pregated = m_gate && WG == 64 && chhi - chlo < 64;
+    const bool pregated = m_gate && (WG == 64 || DIRSPLIT) && chhi - chlo < 64;
     uint64_t gate_pass = ~0ull;  // bit (ch - chlo): the chunk passed the gate
     if (pregated) {
       gate_pass = 0;
@@ -1426,7 +1434,7 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
 #pragma unroll
       for (int dir = 0; dir < 2; ++dir) {  // unrolled: every per-direction array keeps constant indices
         need[dir] = comp[dir] == sc[dir];
-        if (need[dir]) {
+        if (need[dir] && (!DIRSPLIT || uni((int)(threadIdx.x >> 6)) == dir)) {
           StepPlan pl;
           plan_step<P2, false, OffT>(kp, lds, dir, sc[dir] + 1, pl);
           cells += compute_row<P2, false, OffT>(kp, sh, lds, cx, ring_rs, dir, sc[dir] + 1, pl, dirty[dir], a[dir], ext_iters);
@@ -1446,6 +1454,10 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
         dirty[0] = dirty[0] || trim0;
         dirty[1] = dirty[1] || trim1;
         if (trim0 || trim1) {
+          if (DIRSPLIT) {  // the other wave planned that row: its hull is the M row's predicted metadata
+            if (trim0) { const RowMeta mm = get_meta(kp, lds, 0, C_M, sc[0] + 1); plo[0] = mm.lo; phi[0] = mm.hi; }
+            if (trim1) { const RowMeta mm = get_meta(kp, lds, 1, C_M, sc[1] + 1); plo[1] = mm.lo; phi[1] = mm.hi; }
+          }
           if (trim0) trim_pass<P2, false, OffT>(kp, cx, ring_mem, 0, sc[0] + 1, plo[0], phi[0], a[0]);
           if (trim1) trim_pass<P2, false, OffT>(kp, cx, ring_mem, 1, sc[1] + 1, plo[1], phi[1], a[1]);
           __syncthreads();
@@ -1488,7 +1500,10 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
     }
     if (++steps > max_steps) { rc = ST_MAX_STEPS; break; }
   }
-  if (tid == 0) {
+  if (DIRSPLIT) {
+    if ((tid & 63) == 0) atomicAdd(&lstats[STAT_CELLS], cells);
+    if (tid == 0) lstats[STAT_BREAKPOINTS] += 1;
+  } else if (tid == 0) {
     lstats[STAT_CELLS] += cells;
     lstats[STAT_BREAKPOINTS] += 1;
   }

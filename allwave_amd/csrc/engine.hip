@@ -7,11 +7,18 @@
 #include "allwave_hip.h"
 // the device code, once per workgroup size: awv:: one wave per pair (throughput), awvw:: four waves per pair,
 // awvx:: sixteen waves per pair (one pair per CU: the few pairs a large length difference makes enormous)
+#ifndef AWV_THRU_WG
+#define AWV_THRU_WG 64  // 128: two waves per pair, one per search direction (AWV_DIRSPLIT)
+#endif
 #define AWV_NS awv
-#define AWV_WG 64
+#define AWV_WG AWV_THRU_WG
+#if AWV_THRU_WG == 128
+#define AWV_DIRSPLIT 1
+#endif
 #include "biwfa_device.hpp"
 #undef AWV_NS
 #undef AWV_WG
+#undef AWV_DIRSPLIT
 #define AWV_NS awvw
 #define AWV_WG 256
 #include "biwfa_device.hpp"
@@ -390,7 +397,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     auto run_group = [&](std::vector<int32_t> hq, std::vector<int32_t> ht, std::vector<int32_t> hrc, std::vector<uint64_t> hoff,
                          std::vector<int64_t> amap, int waves, int g_maxsum, int g_maxlen, bool reserve_only) -> int {
     if (hq.empty()) return AWV_OK;
-    const int wg = 64 * waves;
+    const int wg = waves == 1 ? AWV_THRU_WG : 64 * waves;
     const int nslots_g = e->cfg.workgroups > 0 ? std::max(1, e->cfg.workgroups / (wg / 64)) : (WAVES_PER_SIMD * 256 / wg) * e->num_cus;
     const int wcap_full = ((g_maxsum + 9 + 256 + 2 * COL_PAD) + 255) & ~255;
     const int nslots_want = (int)std::min<int64_t>(nslots_g, (int64_t)hq.size());
@@ -628,7 +635,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
         for (int g = 0; g < 3; ++g) {
           demand[g] = {0, g};
           if (q[g].empty()) continue;
-          const int wgx = 64 * waves_of[g];
+          const int wgx = waves_of[g] == 1 ? AWV_THRU_WG : 64 * waves_of[g];
           const int64_t slots = std::min<int64_t>((WAVES_PER_SIMD * 256 / wgx) * e->num_cus, (int64_t)q[g].size());
           demand[g].first = (size_t)slots * (size_t)gsum[g] * (glen[g] < 32760 ? 2 : 4);
         }
