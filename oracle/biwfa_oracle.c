@@ -400,6 +400,7 @@ static bool wf_compute(wf_aligner_t* a, int score) {
   wf_offset_t* po_i1 = out_i1->mem - out_i1->alo;
   wf_offset_t* po_d1 = out_d1->mem - out_d1->alo;
   if (!p2) {
+#pragma GCC ivdep
     for (int k = lo; k <= hi; ++k) {
       const wf_offset_t ins1 = MAXI(pm_open1[k - 1], pi1_ext[k - 1]) + 1;
       po_i1[k] = ins1;
@@ -418,6 +419,7 @@ static bool wf_compute(wf_aligner_t* a, int score) {
     const wf_offset_t* pd2_ext = d2_ext->mem - d2_ext->alo;
     wf_offset_t* po_i2 = out_i2->mem - out_i2->alo;
     wf_offset_t* po_d2 = out_d2->mem - out_d2->alo;
+#pragma GCC ivdep
     for (int k = lo; k <= hi; ++k) {
       const wf_offset_t ins1 = MAXI(pm_open1[k - 1], pi1_ext[k - 1]) + 1;
       po_i1[k] = ins1;
@@ -438,17 +440,19 @@ static bool wf_compute(wf_aligner_t* a, int score) {
     }
   }
   if (a->fast_overlap) { /* any non-NULL value out of bounds at this score? (the M candidate is the max of all) */
-    bool oob = false;
+    int oob = 0;
     const wf_offset_t* pi1 = po_i1; const wf_offset_t* pd1 = po_d1;
-    for (int k = lo; k <= hi && !oob; ++k) {
+    const wf_offset_t* pi2 = p2 ? out_i2->mem - out_i2->alo : pi1;
+    const wf_offset_t* pd2 = p2 ? out_d2->mem - out_d2->alo : pd1;
+#pragma GCC ivdep
+    for (int k = lo; k <= hi; ++k) {
       const int hmax = MINI((int)tlen, (int)plen + k);
-      wf_offset_t mx = MAXI(pi1[k], pd1[k]);
-      if (p2) { mx = MAXI(mx, MAXI(out_i2->mem[k - out_i2->alo], out_d2->mem[k - out_d2->alo])); }
+      wf_offset_t mx = MAXI(MAXI(pi1[k], pd1[k]), MAXI(pi2[k], pd2[k]));
       const wf_offset_t mm = pm_misms[k] + 1;
-      if (mm > mx) mx = mm;
-      if (mx >= 0 && mx > hmax) oob = true;
+      mx = MAXI(mx, mm);
+      oob |= (mx >= 0) & (mx > hmax);
     }
-    out_m->saw_oob = oob;
+    out_m->saw_oob = oob != 0;
     out_m->max_ak = 0;
   }
   /* wavefront_compute_process_ends */
