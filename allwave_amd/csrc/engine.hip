@@ -458,7 +458,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
         size_t free_b = 0, total_b = 0;
         e->ring_mem.release();
         (void)hipMemGetInfo(&free_b, &total_b);
-        int ncand = getenv("AWV_NO_ARENA_PROBE") ? 1 : 4;
+        int ncand = (getenv("AWV_NO_ARENA_PROBE") || (e->cfg.flags & AWV_F_NO_ARENA_PROBE)) ? 1 : 4;
         while (ncand > 1 && (size_t)ncand * want > free_b / 10 * 8) --ncand;  // all candidates are alive at once
         const bool probe_ok = ncand > 1 && want >= ((size_t)1 << 30) && esz == 2 && ring_stride >= (size_t)2 * 5 * 32 * 4096 &&
                               (size_t)wc * esz >= 4096;
@@ -563,6 +563,8 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       if (lrc != AWV_OK) return lrc;
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(e->ev1, e->stream));
+      // while the kernel runs: get the host CIGAR buffer's pages in place (0.2 s for config 2's 670 MB)
+      if (sink && !(e->cfg.flags & AWV_F_KEEP_ON_DEVICE) && e->h_cigar.size() < (size_t)arena + 64) e->h_cigar.resize((size_t)arena + 64);
       HIP_TRY(hipEventSynchronize(e->ev1));
       HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
       kernel_ms += ms;

@@ -3,6 +3,7 @@
 #include "planner.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstdio>
 #include <cstring>
@@ -177,6 +178,7 @@ namespace {
 // One engine per device and process, created on first use and kept (like the reference's cached
 // per-thread aligners, alignment.rs:11-22): its HBM arenas are tens of GB, and allocating them right
 // after a free can take the driver seconds.  A holder owns the device's engine for its lifetime.
+std::atomic<int> g_engine_flags{0};  // awv_engine_config.flags of engines created from now on (set_engine_flags)
 struct EngineHolder {
   awv_engine* e = nullptr;
   std::unique_lock<std::mutex> lock;
@@ -196,6 +198,7 @@ struct EngineHolder {
     if (!slot.first) {
       awv_engine_config cfg{};
       cfg.device = device;
+      cfg.flags = g_engine_flags.load();
       if (awv_engine_create(&cfg, &slot.first) != AWV_OK) throw AlignmentError(std::string("engine: ") + awv_last_error());
     }
     e = slot.first;
@@ -273,6 +276,7 @@ AllPairIterator AllPairIterator::with_options(const std::vector<Sequence>& seque
 AllPairIterator& AllPairIterator::with_orientation_params(AlignmentParams p) { orientation_params_ = std::move(p); return *this; }
 AllPairIterator& AllPairIterator::with_orientation(Orientation o) { orientation_ = o; return *this; }
 AllPairIterator& AllPairIterator::with_device(int device) { device_ = device; return *this; }
+void set_engine_flags(int flags) { g_engine_flags.store(flags); }
 
 void AllPairIterator::run(const std::function<void(int64_t, int64_t, const awv_result*, const uint8_t*,
                                                    const std::vector<uint8_t>&)>& batch_cb) {

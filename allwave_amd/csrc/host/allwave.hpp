@@ -85,6 +85,10 @@ enum class Orientation {
 
 using Callback = std::function<void(AlignmentResult&&)>;  // may throw: first error aborts the run
 
+// awv_engine_config.flags (AWV_F_*) for the per-device engines this library creates from now on
+// (an engine lives for the rest of the process once created).
+void set_engine_flags(int flags);
+
 class AllPairIterator {  // iterator.rs:12-149
  public:
   AllPairIterator(const std::vector<Sequence>& sequences, AlignmentParams params);  // ::new

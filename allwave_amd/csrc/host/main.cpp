@@ -179,6 +179,9 @@ int main(int argc, char** argv) {
     if (a.forward_only) it.with_orientation(Orientation::ForwardOnly);
     it.with_device(a.device);
     const size_t total = it.pair_count();
+    // a short-lived process with little work: taking the ring arena as it comes beats choosing the
+    // fastest of four candidates (1-3 s once per engine for up to 6 % of the kernel time)
+    if (total < 2000000) set_engine_flags(AWV_F_NO_ARENA_PROBE);
     std::ofstream fout;
     if (a.have_output) {
       fout.open(a.output, std::ios::binary);

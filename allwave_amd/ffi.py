@@ -18,6 +18,7 @@ AWV_F_FORCE_INT32 = 2
 AWV_F_NO_PACKED_SEQ = 4
 AWV_F_ONE_WAVE = 8
 AWV_F_FOUR_WAVES = 16
+AWV_F_NO_ARENA_PROBE = 32
 
 #: every symbol include/allwave_hip.h declares
 EXPORTS = ("awv_abi_version", "awv_last_error", "awv_engine_create", "awv_engine_destroy",

@@ -33,6 +33,21 @@ def test_struct_layouts_match_header():
     assert C.sizeof(ffi.Stats) == 8 * 26
 
 
+def test_flag_and_status_constants_match_header():
+    """Every AWV_F_* / AWV_ST_* / AWV_ERR_* value the ctypes binding uses is the header's."""
+    import re
+    from allwave_amd import ffi
+    hdr = open(os.path.join(ROOT, "include", "allwave_hip.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(AWV_[A-Z0-9_]+)\s+\(?(-?\d+)\)?", hdr)}
+    flags = [k for k in defs if k.startswith("AWV_F_")]
+    assert len(flags) >= 6 and "AWV_F_NO_ARENA_PROBE" in flags
+    for k in defs:
+        if hasattr(ffi, k):
+            assert getattr(ffi, k) == defs[k], k
+    for k in flags:
+        assert hasattr(ffi, k), k
+
+
 def test_code_object_is_gfx950(hip_lib):
     from allwave_amd import ffi
     blob = open(ffi.LIB_PATH, "rb").read()
