@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -307,7 +308,9 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   int ring = 4;
   while (ring < dp.scope + 2) ring *= 2;
   const int64_t max_batch = e->cfg.max_batch_pairs > 0 ? e->cfg.max_batch_pairs : (int64_t)1 << 20;
-  const uint64_t max_arena = e->cfg.max_arena_bytes > 0 ? (uint64_t)e->cfg.max_arena_bytes : (uint64_t)8 << 30;
+  uint64_t max_arena = e->cfg.max_arena_bytes > 0 ? (uint64_t)e->cfg.max_arena_bytes : (uint64_t)8 << 30;
+  if (const char* env = getenv("AWV_MAX_ARENA_MB")) max_arena = std::max<uint64_t>(1, (uint64_t)atoll(env)) << 20;  // experiment knob
+  const bool inline_sink = getenv("AWV_INLINE_SINK") != nullptr;  // experiment knob: every sink on the calling thread
   // base-case capacities: score_remaining <= 250 or both lengths <= 100
   // A sub-problem that ends in an indel component pays that gap's open on top of the
   // score_remaining its parent hands down (the reverse aligner starts with the open pre-paid).
@@ -334,6 +337,23 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   double kernel_ms = 0, h2d_ms = 0, d2h_ms = 0;
   unsigned long long stat_tot[STAT_N] = {0};
   uint64_t launches = 0;
+  // With several batches in a call, the sink of batch i (the caller's formatting and output) runs on a
+  // helper thread while batch i+1 is carved, launched and copied back.  It is joined before the next
+  // sink starts: sinks never overlap, come in batch order, and a batch's result / CIGAR buffers stay
+  // untouched until its sink has returned.  The last batch's sink runs on the calling thread.
+  struct SinkRunner {
+    std::thread th;
+    int rc = 0;
+    std::vector<awv_result> res;
+    std::vector<uint8_t> cig;
+    int wait() {
+      if (th.joinable()) th.join();
+      const int r = rc;
+      rc = 0;
+      return r;
+    }
+    ~SinkRunner() { if (th.joinable()) th.join(); }
+  } runner;
   while (first < npairs) {
     // ---- carve a batch
     int64_t n = 0;
@@ -667,9 +687,21 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     lap("cigars on host");
     if (out) std::memcpy(out + first, hres.data(), (size_t)n * sizeof(awv_result));
     if (sink) {
-      const int rc = sink(user, first, n, hres.data(), want_cigar ? e->h_cigar.data() : nullptr);
-      if (rc != 0) return fail(AWV_ERR_SINK, "sink callback returned " + std::to_string(rc));
-      lap("sink returned");
+      if (const int prc = runner.wait()) return fail(AWV_ERR_SINK, "sink callback returned " + std::to_string(prc));
+      if (first + n >= npairs || inline_sink) {  // the last (or only) batch: on the calling thread
+        const int rc = sink(user, first, n, hres.data(), want_cigar ? e->h_cigar.data() : nullptr);
+        if (rc != 0) return fail(AWV_ERR_SINK, "sink callback returned " + std::to_string(rc));
+        lap("sink returned");
+      } else {  // hand the batch's buffers to the helper thread and go on with the next batch
+        runner.res.swap(hres);
+        runner.cig.swap(e->h_cigar);
+        const awv_result* rp = runner.res.data();
+        const uint8_t* cp = want_cigar ? runner.cig.data() : nullptr;
+        const int64_t f0 = first, n0 = n;
+        SinkRunner* rn = &runner;
+        runner.th = std::thread([rn, sink, user, f0, n0, rp, cp]() { rn->rc = sink(user, f0, n0, rp, cp); });
+        lap("sink handed off");
+      }
     }
     first += n;
   }

@@ -114,8 +114,12 @@ typedef struct {
   int32_t t_end;          /* #M + #X + #I */
 } awv_result;
 
-/* Sink: called once per launch batch from the calling thread with results[first..first+n)
- * and the batch's CIGAR arena (valid only during the call).  Return non-zero to stop. */
+/* Sink: called once per launch batch with results[first..first+n) and the batch's CIGAR arena
+ * (valid only during the call).  Calls never overlap and come in batch order; with several batches
+ * in one awv_align_pairs call all but the last come from an engine-owned helper thread while the
+ * next batch is being aligned (the reference's callback is invoked from worker threads too,
+ * src/iterator.rs:208-252).  Return non-zero to stop: the call then fails with AWV_ERR_SINK before
+ * any further sink call. */
 typedef int (*awv_sink)(void* user, int64_t first, int64_t n, const awv_result* results,
                         const uint8_t* cigar_arena);
 
