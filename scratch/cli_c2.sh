@@ -29,7 +29,7 @@ for knob in "AWV_INLINE_SINK=1" "AWV_PIPELINED=1"; do
     env AWV_MAX_ARENA_MB=170 $knob timeout -k 10 200 ./allwave_amd/allwave_hip -i /tmp/c2.fa -o /tmp/c2b.paf -p none -s 0,5,8,2,24,1 -t 16 --forward-only 2> /tmp/c2.err || { tail -3 /tmp/c2.err; exit 1; }
     e=$(date +%s.%N)
     cmp -s /tmp/c2_fwd.paf /tmp/c2b.paf && same=identical || same=DIFFERENT
-    python -c "t=$e-$s; print('cli c2 4 batches $knob run $rep: %.2f s wall, PAF $same to the one-batch run's' % t)"
+    python -c "t=$e-$s; print('cli c2 4 batches $knob run $rep: %.2f s wall, PAF $same to the one-batch run' % t)"
     grep -E "sink|aligned" /tmp/c2.err | tail -3
   done
 done
