@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("AWV_HIP_LIB") or os.path.join(_HERE, "liballwave_hip.
 
 AWV_OK = 0
 AWV_ERR_NO_DEVICE = -1
+AWV_ERR_SINK = -7
 AWV_F_KEEP_ON_DEVICE = 1
 AWV_F_FORCE_INT32 = 2
 AWV_F_NO_PACKED_SEQ = 4

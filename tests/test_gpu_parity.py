@@ -166,6 +166,37 @@ def test_engine_stats_and_batching(engine):
     assert (r1["penalty"] == r2["penalty"]).all() and c1 == c2
 
 
+def test_sink_error_stops_the_call():
+    """A sink that returns non-zero ends the call with AWV_ERR_SINK and no later sink call (first error
+    wins, iterator.rs:236-251) -- also when the failing sink ran on the engine's helper thread, which
+    takes every batch but the last of a call of several batches."""
+    import ctypes as C
+    from allwave_amd import ffi, synth
+    data, offs, _ = synth.generate(10, 800, 0.05, 9)
+    pairs = synth.all_pairs(10)  # 90 pairs: 13 batches of at most 7
+    p = np.zeros(len(pairs), dtype=ffi.PAIR_DTYPE)
+    p["q_idx"], p["t_idx"] = pairs[:, 0], pairs[:, 1]
+    pen = ffi.Penalties.from_scores(DEFAULT_2P)
+    e2 = ffi.Engine(max_batch_pairs=7)
+    try:
+        e2.set_sequences((data, offs))
+        for fail_at in (0, 1, 12):
+            firsts = []
+
+            def sink(user, first, n, rptr, arena):
+                firsts.append(int(first))
+                return 7 if len(firsts) - 1 == fail_at else 0
+
+            cb = ffi.SINK_FN(sink)
+            rc = ffi.load().awv_align_pairs(e2._h, C.byref(pen), p.ctypes.data, len(p), None, cb, None)
+            assert rc == ffi.AWV_ERR_SINK, (fail_at, rc)
+            assert firsts == [7 * i for i in range(fail_at + 1)], (fail_at, firsts)
+        r, c = e2.align_pairs(DEFAULT_2P, pairs)  # the engine is usable afterwards
+        assert (r["status"] == 0).all() and all(x is not None for x in c)
+    finally:
+        e2.close()
+
+
 def test_bad_arguments(engine):
     from allwave_amd import ffi
     engine.set_sequences([b"ACGT", b"ACGA"])
