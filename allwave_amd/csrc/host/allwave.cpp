@@ -277,6 +277,14 @@ AllPairIterator& AllPairIterator::with_orientation_params(AlignmentParams p) { o
 AllPairIterator& AllPairIterator::with_orientation(Orientation o) { orientation_ = o; return *this; }
 AllPairIterator& AllPairIterator::with_device(int device) { device_ = device; return *this; }
 void set_engine_flags(int flags) { g_engine_flags.store(flags); }
+AllPairIterator& AllPairIterator::with_shard(size_t rank, size_t world) {
+  if (world <= 1) return *this;
+  std::vector<std::pair<size_t, size_t>> mine;
+  mine.reserve(pairs_.size() / world + 1);
+  for (size_t i = rank; i < pairs_.size(); i += world) mine.push_back(pairs_[i]);
+  pairs_.swap(mine);
+  return *this;
+}
 
 void AllPairIterator::run(const std::function<void(int64_t, int64_t, const awv_result*, const uint8_t*,
                                                    const std::vector<uint8_t>&)>& batch_cb) {

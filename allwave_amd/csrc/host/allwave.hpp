@@ -97,6 +97,9 @@ class AllPairIterator {  // iterator.rs:12-149
   AllPairIterator& with_orientation_params(AlignmentParams p);
   AllPairIterator& with_orientation(Orientation o);
   AllPairIterator& with_device(int device);
+  // keep pairs rank, rank + world, ... of the planned list (one process per GPU: every pair lands on
+  // exactly one rank, per-rank cost stays even for a row-major all-pairs list)
+  AllPairIterator& with_shard(size_t rank, size_t world);
   size_t pair_count() const { return pairs_.size(); }
   const std::vector<std::pair<size_t, size_t>>& get_pairs() const { return pairs_; }
   // iterator.rs:127-137,206-253: streams results (order unspecified in the reference for T>1;

@@ -25,6 +25,7 @@ struct Args {
   bool have_output = false, have_scores = false, have_preset = false, no_progress = false, mash_matrix = false;
   bool wfa_orientation = false, forward_only = false, have_keep = false, have_exclude = false;
   int threads = 1, device = 0;
+  long shard_rank = 0, shard_world = 1;  // --shard R/N: this process aligns pairs R, R+N, ... (one process per GPU)
 };
 
 [[noreturn]] void die(const std::string& m, int code = 2) {
@@ -128,9 +129,18 @@ int main(int argc, char** argv) {
     else if (k == "-k" || k == "--keep-prefixes") { a.keep = val(); a.have_keep = true; }
     else if (k == "-e" || k == "--exclude-prefixes") { a.exclude = val(); a.have_exclude = true; }
     else if (k == "--device") a.device = atoi(val().c_str());
+    else if (k == "--shard") {
+      const std::string v = val();
+      char* end = nullptr;
+      a.shard_rank = strtol(v.c_str(), &end, 10);
+      if (!end || *end != '/') die("--shard expects R/N, e.g. 3/8");
+      const char* w = end + 1;
+      a.shard_world = strtol(w, &end, 10);
+      if (end == w || *end != 0 || a.shard_world < 1 || a.shard_rank < 0 || a.shard_rank >= a.shard_world) die("--shard expects R/N with 0 <= R < N");
+    }
     else if (k == "-h" || k == "--help") {
       std::cout << "usage: allwave_hip -i in.fa [-o out.paf] [-s m,x,o,e[,o2,e2] | -x ANI] [-p none|auto|random:f|giant:p|tree:n:f:r[:k]]\n"
-                   "                   [-t threads] [--wfa-orientation|--forward-only] [-k prefixes | -e prefixes] [--mash-matrix] [--device N]\n";
+                   "                   [-t threads] [--wfa-orientation|--forward-only] [-k prefixes | -e prefixes] [--mash-matrix] [--device N] [--shard R/N]\n";
       return 0;
     } else die("unexpected argument: " + k);
   }
@@ -178,6 +188,7 @@ int main(int argc, char** argv) {
     AllPairIterator it = AllPairIterator::with_options(sequences, params, true, !a.wfa_orientation, strategy);
     if (a.forward_only) it.with_orientation(Orientation::ForwardOnly);
     it.with_device(a.device);
+    it.with_shard((size_t)a.shard_rank, (size_t)a.shard_world);
     const size_t total = it.pair_count();
     // a short-lived process with little work: taking the ring arena as it comes beats choosing the
     // fastest of four candidates (1-3 s once per engine for up to 6 % of the kernel time)

@@ -169,6 +169,15 @@ def test_cli_end_to_end(host, oracle, tmp_path):
     strand = {(l.split("\t")[0], l.split("\t")[5]): l.split("\t")[4] for l in lines}
     assert strand[("grpB_1", "grpA_1")] == "-" and strand[("grpA_2", "grpA_1")] == "+" and strand[("grpA_1", "grpB_1")] == "-"
     assert lines == host.all_pairs_paf(ids, seqs, "0,5,8,2,24,1", orientation="mash")
+    # one process per GPU: --shard R/N keeps pairs R, R+N, ... -- the shards together are the whole run
+    shards = []
+    for r in range(3):
+        o = subprocess.run([build.CLI_BIN, "-i", str(fa2), "-p", "none", "--no-progress", "--shard", "%d/3" % r], capture_output=True, text=True, timeout=300)
+        assert o.returncode == 0, o.stderr
+        assert len(o.stdout.splitlines()) == 4
+        shards += o.stdout.splitlines()
+    assert sorted(shards) == sorted(lines)
+    assert subprocess.run([build.CLI_BIN, "-i", str(fa2), "--shard", "3/3"], capture_output=True, text=True, timeout=60).returncode != 0
     out = subprocess.run([build.CLI_BIN, "-i", str(fa2), "-p", "none", "-k", "grpA", "--wfa-orientation", "-o", str(tmp_path / "o.paf")],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "Kept sequences with prefixes: 4 -> 2" in out.stderr
