@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -699,8 +700,13 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
         const uint8_t* cp = want_cigar ? runner.cig.data() : nullptr;
         const int64_t f0 = first, n0 = n;
         SinkRunner* rn = &runner;
-        runner.th = std::thread([rn, sink, user, f0, n0, rp, cp]() { rn->rc = sink(user, f0, n0, rp, cp); });
-        lap("sink handed off");
+        try {
+          runner.th = std::thread([rn, sink, user, f0, n0, rp, cp]() { rn->rc = sink(user, f0, n0, rp, cp); });
+          lap("sink handed off");
+        } catch (const std::exception&) {  // no thread to be had: this sink runs here, nothing may cross the C boundary
+          const int rc = sink(user, f0, n0, rp, cp);
+          if (rc != 0) return fail(AWV_ERR_SINK, "sink callback returned " + std::to_string(rc));
+        }
       }
     }
     first += n;
