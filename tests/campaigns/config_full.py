@@ -19,6 +19,9 @@ from oracle import oracle as O
 
 cfgname = sys.argv[1] if len(sys.argv) > 1 else "c2"
 cfg = synth.CONFIGS[cfgname]
+if os.environ.get("CFG_SCORES"):  # another penalty set on the same read set, e.g. the CLI's ANI presets (main.rs:83-124)
+    cfg = dict(cfg, scores=tuple(int(x) for x in os.environ["CFG_SCORES"].split(",")))
+    cfgname += "[" + os.environ["CFG_SCORES"] + "]"
 kw = {"mixed_lengths": cfg["mixed_lengths"]} if "mixed_lengths" in cfg else {}
 data, offs, ids = synth.generate(cfg["nseq"], cfg["length"], cfg["d"], cfg["seed"], **kw)
 if cfg["sparsify"] == "none":
