@@ -276,9 +276,10 @@ def test_wide_scope_penalties(engine, oracle, scores):
 
 
 def test_config3_shaped_batches():
-    """BASELINE config 3's shape (4096 x 10 kbp, 5 %), a 40 k-pair random slice of its all-pairs list,
+    """BASELINE configs[2] (config 3: 4096 x 10 kbp, 5 %), a 40 k-pair random slice of its all-pairs list,
     CIGAR arena capped so that the call takes several launches: every pair completes, the CIGAR
-    consumes both sequences, op counts add up, and penalty(a, b) == penalty(b, a)."""
+    consumes both sequences, op counts add up, and penalty(a, b) == penalty(b, a); the first 256
+    pairs of the slice are compared with the oracle bit for bit."""
     from allwave_amd import ffi, synth
     cfg = synth.CONFIGS["c3"]
     data, offs, _ = synth.generate(cfg["nseq"], cfg["length"], cfg["d"], cfg["seed"])
@@ -300,6 +301,26 @@ def test_config3_shaped_batches():
         assert (res["q_end"] == ql).all() and (res["t_end"] == tl).all()
         assert (res["num_matches"] + res["num_mismatches"] + res["num_ins"] + res["num_del"] == res["cigar_len"]).all()
         assert (res["penalty"][0::2] == res["penalty"][1::2]).all()
+        # ... and 256 pairs of config 3's own read set against the oracle: penalty, op counts and the
+        # FNV-1a of the op bytes, pair by pair (the oracle's thread-pool driver, allpairs_cpu.c)
+        from oracle import oracle as O
+        sub = np.ascontiguousarray(pairs[:256])
+        e2 = ffi.Engine()
+        try:
+            e2.set_sequences((data, offs))
+            gres, gcigs = e2.align_pairs(cfg["scores"], sub)
+        finally:
+            e2.close()
+        _, ores, _, _ = O.all_pairs(data, offs, sub, cfg["scores"], nthreads=min(16, os.cpu_count() or 1))
+        assert (gres["status"] == 0).all() and (ores["status"] == 0).all()
+        assert (gres["penalty"] == ores["penalty"]).all()
+        assert (gres["penalty"] == res["penalty"][:256]).all()  # the capped multi-launch run gave the same answers
+        assert (gres["cigar_len"] == ores["cigar_len"].astype(np.uint32)).all()
+        for k_g, k_o in (("num_matches", "num_matches"), ("num_mismatches", "num_mismatches"),
+                         ("num_ins", "num_ins_text"), ("num_del", "num_del_pattern")):
+            assert (gres[k_g] == ores[k_o]).all(), k_g
+        for i in range(len(sub)):
+            assert O.fnv1a(gcigs[i]) == int(ores["cigar_hash"][i]), ("config 3 pair", tuple(sub[i]))
     finally:
         e.close()
 
@@ -328,6 +349,42 @@ def test_config5_shaped_sparsified_mixed_lengths(engine, oracle):
     pairs = [tuple(int(v) for v in p) for p in H.plan_pairs(ids, seqs, "tree:3:1:0.1")]
     assert 20 <= len(pairs) < 20 * 19
     check_against_oracle(engine, oracle, seqs, pairs, DEFAULT_2P)
+
+
+def test_config5_real_lengths(oracle):
+    """BASELINE configs[4] (config 5) at its REAL lengths: 512 prefixes of 1-50 kbp of a common root at
+    10 %, pair list from the planner's `-p tree:3:1:0.1` (iterator.rs:30-50 -> knn_graph.rs); eight
+    pairs of that list -- the shortest query against the longest target it meets, the longest against
+    the shortest, and a spread in between: forced gaps of tens of kbp, 16- and 32-bit rows and the
+    wide flavours in one call -- against the oracle bit for bit."""
+    from allwave_amd import ffi, host as H, synth
+    cfg = synth.CONFIGS["c5"]
+    data, offs, ids = synth.generate(cfg["nseq"], cfg["length"], cfg["d"], cfg["seed"], mixed_lengths=cfg["mixed_lengths"])
+    lens = (offs[1:] - offs[:-1]).astype(np.int64)
+    assert lens.min() < 1500 and lens.max() > 48000
+    seqs = [bytes(data[offs[i]:offs[i + 1]]) for i in range(cfg["nseq"])]
+    plist = np.asarray(H.plan_pairs(ids, seqs, cfg["sparsify"]), dtype=np.int32)[:, :2]
+    assert 10000 < len(plist) < 60000
+    dl = lens[plist[:, 0]] - lens[plist[:, 1]]
+    order = np.argsort(dl, kind="stable")
+    pick = [order[0], order[-1]] + [order[int(f * (len(order) - 1))] for f in (0.02, 0.25, 0.5, 0.75, 0.98)]
+    pick.append(int(np.argmin(lens[plist[:, 0]] + lens[plist[:, 1]])))
+    sub = np.ascontiguousarray(plist[pick])
+    assert abs(int(dl[order[0]])) > 30000 and abs(int(dl[order[-1]])) > 30000
+    e = ffi.Engine()
+    try:
+        e.set_sequences((data, offs))
+        gres, gcigs = e.align_pairs(cfg["scores"], sub)
+        st = e.stats()
+        assert st.launches >= 2  # more than one kernel flavour / row width in the call
+    finally:
+        e.close()
+    _, ores, _, _ = oracle.all_pairs(data, offs, sub, cfg["scores"], nthreads=min(8, os.cpu_count() or 1), fast_overlap=True)
+    assert (gres["status"] == 0).all() and (ores["status"] == 0).all()
+    assert (gres["penalty"] == ores["penalty"]).all(), (gres["penalty"], ores["penalty"])
+    assert (gres["q_end"] == lens[sub[:, 0]]).all() and (gres["t_end"] == lens[sub[:, 1]]).all()
+    for i in range(len(sub)):
+        assert oracle.fnv1a(gcigs[i]) == int(ores["cigar_hash"][i]), ("config 5 pair", tuple(sub[i]), int(lens[sub[i, 0]]), int(lens[sub[i, 1]]))
 
 
 @pytest.mark.parametrize("length", [32759, 32760])
