@@ -57,7 +57,7 @@ constexpr int STACK_CAP = 48;
 #define AWV_WAVES_PER_SIMD 4
 #endif
 constexpr int WAVES_PER_SIMD = AWV_WAVES_PER_SIMD;
-constexpr int STATIC_LDS_RESERVE = 640;
+constexpr int STATIC_LDS_RESERVE = 1024;
 constexpr int COL_PAD = 576;  // columns of slack either side of a row: whole-wave vector loads stay inside it
 
 // per-pair status (allwave_hip.h AWV_ST_*)
@@ -78,7 +78,7 @@ enum { STAT_CELLS = 0, STAT_EXTEND, STAT_BREAKPOINTS, STAT_BASE, STAT_OVERLAP, S
        // cycle stamps (s_memtime, wave 0) -- only filled by the -DAWV_PROF diagnostic build
        STAT_T_TOTAL, STAT_T_BI_COMPUTE, STAT_T_BI_BARRIER, STAT_T_BI_FINALIZE, STAT_T_OVERLAP, STAT_T_BASE_STEPS,
        STAT_T_BACKTRACE, STAT_T_EMIT, STAT_N_PASSES,
-       STAT_T_CR_LOAD, STAT_T_CR_ALU, STAT_T_CR_EXTEND, STAT_T_CR_STORE, STAT_T_CR_REDUCE, STAT_N };
+       STAT_T_CR_LOAD, STAT_T_CR_ALU, STAT_T_CR_EXTEND, STAT_T_CR_STORE, STAT_T_CR_REDUCE, STAT_RESTARTS, STAT_MULTI_CELLS, STAT_WIN_SINGLE, STAT_WIN_MULTI, STAT_WIN_BASE, STAT_N };
 
 #ifdef AWV_PROF
 #define PROF_DRAIN() __builtin_amdgcn_s_waitcnt(0)
@@ -106,7 +106,8 @@ struct KParams {
   const int32_t* pair_rc;
   long long npairs;
   DevPenalties pen;
-  int ring;        // power of two >= scope + 2
+  int ring;        // power of two >= scope + 2 (+ multi_T - 1 with multi-step passes)
+  int multi_T;     // steps per multi-step pass (0: off): <= min(TMAX, x, o1+e1, o2+e2, ring - scope - 1), e1/e2 among the instantiated depths
   int wcap;        // columns per ring row
   void* ring_mem;
   size_t ring_slot_stride;  // bytes per workgroup slot
@@ -129,7 +130,7 @@ struct KParams {
 struct RowMeta { int lo, hi; };
 constexpr int K_BIG = 1 << 28;  // an empty row is {K_BIG, -K_BIG}: min/max hulls ignore it for free
 #define ROW_EMPTY RowMeta{K_BIG, -K_BIG}
-struct Acc { int hull_lo[NCOMP]; int hull_hi[NCOMP]; int maxak; int oob; };
+struct Acc { int hull_lo[NCOMP]; int hull_hi[NCOMP]; int maxak; int oob; int maxak_t[8]; };  // maxak_t: per step of a multi-step pass
 struct Task { int pb, pe, tb, te, cb, ce, score_remaining, known; };  // known: the sub-problem's optimal score (INT_MAX at the top)
 struct Breakpoint { int score, sf, sr, kf, kr, off_f, off_r, comp; };
 
@@ -160,8 +161,26 @@ struct Lds {
   uint32_t* seq;   // sequence staging: the sub-problem's 2-bit packed words (16 bases per word)
   RowMeta* meta_log;  // HBM: [score][NCOMP] of the running base case
 };
+// What a multi-step pass (multi_pass: a real function with registers of its own) needs to know about
+// the kernel's parameters and the running sub-problem: written to LDS by find_breakpoint, read back
+// into scalar registers inside the pass.
+struct PassCtx {
+  unsigned long long ring_mem;   // this workgroup's ring arena
+  unsigned long long ring_bytes;
+  unsigned long long P[2], T[2]; // SubCtx::P / T (raw-byte probes)
+  int ring, wcap;
+  int x, o1, e1, o2, e2;
+  int lds_meta_bytes;
+  int plen, tlen, kmin[2], wcols;
+  int seq_mode, p_w0, t_w0, p_bit, t_bit;
+};
+struct PhaseResult { int why, sc, fmax, rmax, npass; unsigned long long cells; };
 struct Shared {
   Acc acc[3][2];
+  PassCtx pctx;
+  PhaseResult pres;
+  unsigned long long ext_multi;  // extend probes counted by multi-step passes
+  unsigned int win_single, win_multi, win_base;  // windows processed (diagnostics)
   int ext0[2];
   unsigned long long prof[5];
   long long cur_pair;
@@ -433,6 +452,8 @@ __device__ __forceinline__ void acc_reset(Acc& a) {
   for (int c = 0; c < NCOMP; ++c) { a.hull_lo[c] = INT_MAX; a.hull_hi[c] = INT_MIN; }
   a.maxak = 0;
   a.oob = 0;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) a.maxak_t[t] = 0;
 }
 
 struct StepPlan {  // uniform description of one compute-next call
@@ -547,6 +568,65 @@ __device__ __forceinline__ RawVec<int32_t> shift_from_right(const RawVec<int32_t
   return o;
 }
 
+// extend (A.4) of one lane vector's four M cells (m[j] < 0: NULL, left alone): the first probe (16 bases)
+// of all four cells is issued together (invalid cells probe offset 0, always readable), then the
+// longer runs continue in a loop
+template <typename OffT>
+__device__ __forceinline__ void extend_cells(const Lds<OffT>& lds, const SubCtx& cx, int dir, int k0, int32_t (&m)[4], unsigned& ext_iters) {
+  constexpr int VEC = 4;
+  const gseq_t Pp = dir ? cx.P[1] : cx.P[0];  // (selects: `dir` may be a run-time value, SubCtx lives in registers)
+  const gseq_t Tp = dir ? cx.T[1] : cx.T[0];
+  const int plen = cx.plen, tlen = cx.tlen;
+  int rr[VEC], vv[VEC], hh[VEC];
+  uint64_t xx[VEC];
+  const bool packed = cx.seq_mode != 0;
+  const uint32_t* seq = lds.seq;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const bool ok = m[j] >= 0;
+    vv[j] = ok ? m[j] - (k0 + j) : 0;
+    hh[j] = ok ? m[j] : 0;
+    rr[j] = ok ? min(plen - vv[j], tlen - hh[j]) : 0;
+  }
+  // uniform branches hoisted out of the per-cell code so the four probes stay back to back
+  int cont = 0;
+  if (packed) {
+    int nn[VEC];
+    if (dir == 0) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) nn[j] = packed_first_count<0>(seq, cx, vv[j], hh[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) nn[j] = packed_first_count<1>(seq, cx, vv[j], hh[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      cont |= (nn[j] == PROBE_FIRST && rr[j] > PROBE_FIRST) ? (1 << j) : 0;
+      m[j] += min(nn[j], rr[j]);  // rr == 0 for NULL cells: unchanged
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) xx[j] = ld64u(Pp + (unsigned)vv[j]) ^ ld64u(Tp + (unsigned)hh[j]);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      int n = xx[j] ? (int)(__builtin_ctzll(xx[j]) >> 3) : PROBE_BYTES;
+      cont |= (n == PROBE_BYTES && rr[j] > PROBE_BYTES) ? (1 << j) : 0;
+      m[j] += min(n, rr[j]);
+    }
+  }
+  ext_iters += VEC;
+  if (cont) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (cont & (1 << j)) {
+        const int v = m[j] - (k0 + j), h = m[j];
+        if (packed) m[j] += dir == 0 ? extend_lcp_packed<0>(seq, cx, v, h, ext_iters) : extend_lcp_packed<1>(seq, cx, v, h, ext_iters);
+        else m[j] += extend_lcp(Pp, Tp, v, h, plen, tlen, ext_iters);
+      }
+    }
+  }
+}
+
 // One compute-next + extend step of one direction (A.3 + A.4).  Every lane owns VEC consecutive
 // diagonals and loads ONE naturally aligned vector per source row; the k-1 / k+1 neighbours are
 // assembled in registers from the adjacent lanes (shift_from_left / shift_from_right), so lanes 0 and
@@ -586,8 +666,6 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
   const int tD1 = row_off<BASE, OffT>(kp, dir, C_D1, score);
   const int tI2 = P2 ? row_off<BASE, OffT>(kp, dir, C_I2, score) : 0;
   const int tD2 = P2 ? row_off<BASE, OffT>(kp, dir, C_D2, score) : 0;
-  const gseq_t Pp = cx.P[dir];
-  const gseq_t Tp = cx.T[dir];
   const int plen = cx.plen, tlen = cx.tlen;
   const int colLo = lo - kmin, colHi = hi - kmin;
   int lane_maxak = 0;
@@ -783,56 +861,7 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_ALU, tc1);
     const unsigned long long tc2 = PROF_NOW();
-    // extend (A.4): the first probe (16 bases) of all four cells is issued together (invalid cells
-    // probe offset 0, always readable), then the longer runs continue in a loop
-    int rr[VEC], vv[VEC], hh[VEC];
-    uint64_t xx[VEC];
-    const bool packed = cx.seq_mode != 0;
-    const uint32_t* seq = lds.seq;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const bool ok = m[j] >= 0;
-      vv[j] = ok ? m[j] - (k0 + j) : 0;
-      hh[j] = ok ? m[j] : 0;
-      rr[j] = ok ? min(plen - vv[j], tlen - hh[j]) : 0;
-    }
-    // uniform branches hoisted out of the per-cell code so the four probes stay back to back
-    int cont = 0;
-    if (packed) {
-      int nn[VEC];
-      if (dir == 0) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) nn[j] = packed_first_count<0>(seq, cx, vv[j], hh[j]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) nn[j] = packed_first_count<1>(seq, cx, vv[j], hh[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        cont |= (nn[j] == PROBE_FIRST && rr[j] > PROBE_FIRST) ? (1 << j) : 0;
-        m[j] += min(nn[j], rr[j]);  // rr == 0 for NULL cells: unchanged
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) xx[j] = ld64u(Pp + (unsigned)vv[j]) ^ ld64u(Tp + (unsigned)hh[j]);
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        int n = xx[j] ? (int)(__builtin_ctzll(xx[j]) >> 3) : PROBE_BYTES;
-        cont |= (n == PROBE_BYTES && rr[j] > PROBE_BYTES) ? (1 << j) : 0;
-        m[j] += min(n, rr[j]);
-      }
-    }
-    ext_iters += VEC;
-    if (cont) {
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        if (cont & (1 << j)) {
-          const int v = m[j] - (k0 + j), h = m[j];
-          if (packed) m[j] += dir == 0 ? extend_lcp_packed<0>(seq, cx, v, h, ext_iters) : extend_lcp_packed<1>(seq, cx, v, h, ext_iters);
-          else m[j] += extend_lcp(Pp, Tp, v, h, plen, tlen, ext_iters);
-        }
-      }
-    }
+    extend_cells<OffT>(lds, cx, dir, k0, m, ext_iters);
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_EXTEND, tc2);
     const unsigned long long tc3 = PROF_NOW();
@@ -845,6 +874,7 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_STORE, tc3);
   }
+  if (threadIdx.x == 0) { const unsigned nw = (unsigned)((colHi - ((colLo & ~(VEC - 1)) - VEC) - VEC) / WSTRIDE + 1); if (BASE) sh.win_base += nw; else sh.win_single += nw; }
   const unsigned long long tc4 = PROF_NOW();
   const int wmax = wave_max_i32(lane_maxak);  // one reduction per row: the row's max antidiagonal
   const bool woob = __any(lane_oob);
@@ -854,6 +884,453 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
   }
   PROF_ADD_L(STAT_T_CR_REDUCE, tc4);
   return hi - lo + 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-step windows (round 2): while the two searches are far apart and no row has been trimmed, a
+// window advances T <= TMAX consecutive scores in one pass.  The I/D rows, which only ever feed the
+// next e1 / e2 steps of their own diagonal neighbourhood, stay in registers for the whole pass; only
+// the M rows (read again x, o1+e1 and o2+e2 steps later) and the pass's last e1 / e2 I/D rows go to
+// HBM.  With T <= min(x, o1+e1, o2+e2) every M source of the pass was written by an earlier pass, so
+// all of its row loads (2(e1+e2) I/D vectors + 3T M vectors) are issued up front in one burst, one
+// memory round trip per T steps instead of one per step.  Per T steps a window moves
+// 2(e1+e2) + 3T loads + T + 2(e1+e2) stores instead of 12T (default penalties, T = 5: 32 instead of
+// 60 lane vectors).  Values a step cannot know -- the +-1 neighbours beyond the window -- creep in by
+// one column per step from both edges, so HALO = ceil(TMAX/4) lanes on either side are recomputed by
+// the neighbouring windows and never stored: a window produces (64 - 2 HALO) * 4 columns.
+// What the overlap search of phase 2 needs (the I/D rows of the last `scope` scores) is not kept by
+// such passes: find_breakpoint leaves this mode a safe margin before the searches can meet and a
+// sub-problem that still runs out of I/D history is searched again step by step (BP_RESTART).
+// A pass in which some value leaves the matrix (the trimmed-hull case) is discarded and redone step by
+// step: nothing it wrote aliases a row a step-by-step redo reads (ring >= scope + TMAX + 1).
+// ---------------------------------------------------------------------------------------------
+#ifndef AWV_TMAX
+#define AWV_TMAX 5
+#endif
+constexpr int TMAX = AWV_TMAX;
+constexpr int MHALO = (TMAX + 3) / 4;       // unproductive lanes on either side of a window
+constexpr int MPROD = 64 - 2 * MHALO;       // productive lanes
+constexpr int MSTRIDE = MPROD * 4;          // new columns per window
+static_assert(TMAX >= 2 && TMAX <= 8, "pass length");
+
+struct MultiPlan {
+  int Tn;                    // steps in this pass
+  int lo[TMAX], hi[TMAX];    // predicted hull of step t (score s0 + 1 + t); lo > hi: empty
+  int lo_min, hi_max;        // union of the step hulls
+  int vlo, vhi;              // VGPR: lane r = source r's stored hull as lane-aligned columns (empty: BIG / -BIG)
+  int int_lo, int_hi;        // window origins whose 64 lane vectors lie inside every source's stored hull
+};
+
+// source r of a pass that starts after score s0: which component at which score
+template <bool P2, int E1, int E2>
+__device__ __forceinline__ void multi_source(const DevPenalties& pn, int s0, int r, int& comp, int& score) {
+  constexpr int NS0 = 2 * E1 + (P2 ? 2 * E2 : 0);
+  if (r < E1) { comp = C_I1; score = s0 - E1 + 1 + r; }
+  else if (r < 2 * E1) { comp = C_D1; score = s0 - E1 + 1 + (r - E1); }
+  else if (P2 && r < 2 * E1 + E2) { comp = C_I2; score = s0 - E2 + 1 + (r - 2 * E1); }
+  else if (P2 && r < NS0) { comp = C_D2; score = s0 - E2 + 1 + (r - 2 * E1 - E2); }
+  else {
+    constexpr int NT = P2 ? 3 : 2;
+    const int t = (r - NS0) / NT, w = (r - NS0) % NT;
+    comp = C_M;
+    score = s0 + 1 + t - (w == 0 ? pn.x : w == 1 ? pn.o1 + pn.e1 : pn.o2 + pn.e2);
+  }
+}
+
+template <bool P2, typename OffT, int E1, int E2>
+__device__ __forceinline__ void plan_multi(const KParams& kp, const Lds<OffT>& lds, const SubCtx& cx, int dir, int s0, int Tn, MultiPlan& mp) {
+  constexpr int NS0 = 2 * E1 + (P2 ? 2 * E2 : 0);
+  constexpr int NT = P2 ? 3 : 2;
+  const DevPenalties& pn = kp.pen;
+  const int kmin = dir ? cx.kmin[1] : cx.kmin[0];
+  mp.Tn = Tn;
+  mp.lo_min = K_BIG;
+  mp.hi_max = -K_BIG;
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    mp.lo[t] = 1;
+    mp.hi[t] = 0;
+    if (t < Tn) {  // (uniform) the predicted metadata of step t is in LDS before step t + 1 is planned
+      StepPlan pl;
+      plan_step<P2, false, OffT>(kp, lds, dir, s0 + 1 + t, pl);
+      mp.lo[t] = pl.lo;
+      mp.hi[t] = pl.hi;
+      if (pl.lo <= pl.hi) {
+        mp.lo_min = min(mp.lo_min, pl.lo);
+        mp.hi_max = max(mp.hi_max, pl.hi);
+      }
+    }
+  }
+  // every source row's stored extent = the hull of the step that wrote it (its M row's metadata; all
+  // source scores are >= 1 here, so no score-0 special case), fetched by lane r in one LDS round trip
+  const int lane = threadIdx.x & 63;
+  const int ns = NS0 + NT * Tn;
+  int comp, score;
+  multi_source<P2, E1, E2>(pn, s0, lane, comp, score);
+  RowMeta h = ROW_EMPTY;
+  if (lane < ns) h = meta_load(&lds.ring_meta[(dir * NCOMP + C_M) * kp.ring + (score & (kp.ring - 1))]);
+  const bool empty = h.lo > h.hi;
+  mp.vlo = empty ? K_BIG : ((h.lo - kmin) & ~3);
+  mp.vhi = empty ? -K_BIG : ((h.hi - kmin) | 3);
+  mp.int_lo = wave_max_i32(lane < ns ? mp.vlo : INT_MIN);
+  mp.int_hi = -wave_max_i32(lane < ns ? -mp.vhi : INT_MIN) - 255;
+}
+
+// One pass: Tn steps of one direction over all windows of the rows.  Returns the number of cells.
+template <bool P2, typename OffT, int E1, int E2>
+__device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh, const Lds<OffT>& lds, const SubCtx& cx, rsrc_t rs,
+                                                  int dir, int s0, const MultiPlan& mp, Acc& acc, unsigned& ext_iters) {
+  static_assert(sizeof(OffT) == 2, "multi-step windows: 16-bit rows");
+  static_assert(E1 >= 1 && E1 <= 2 && E2 >= 1 && E2 <= 2, "register-resident I/D depth");
+  constexpr int NWAVES = WG / 64;
+  constexpr int VEC = 4, ESZ = 2;
+  constexpr int NS0 = 2 * E1 + (P2 ? 2 * E2 : 0);
+  constexpr int NT = P2 ? 3 : 2;
+  typedef RawVec<OffT> V;
+  const DevPenalties& pn = kp.pen;
+  const int lane = threadIdx.x & 63;
+  const int kmin = dir ? cx.kmin[1] : cx.kmin[0];
+  const int plen = cx.plen, tlen = cx.tlen;
+  const int Tn = mp.Tn;
+  if (mp.lo_min > mp.hi_max) return 0;  // all steps empty
+  if (mp.lo_min - kmin < 256 + 1 || mp.hi_max - kmin + 256 + VEC + 2 > cx.wcols) {
+    sh.error = ST_CAPACITY;
+    return 0;
+  }
+  const int colLoMin = mp.lo_min - kmin, colHiMax = mp.hi_max - kmin;
+  const unsigned nullw = ((unsigned)(unsigned short)NULL16) * 0x00010001u;
+  const bool productive = lane >= MHALO && lane < 64 - MHALO;
+  int lane_maxak[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) lane_maxak[t] = 0;
+  bool lane_oob = false;
+  typedef short s2 __attribute__((ext_vector_type(2)));
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  auto as2 = [](unsigned w) { return __builtin_bit_cast(s2, w); };
+  auto asu = [](s2 v) { return __builtin_bit_cast(unsigned, v); };
+  const s2 one = {1, 1};
+  const short tl1 = (short)(tlen + 1);
+  const s2 tlen1 = {tl1, tl1};
+  const us2 null_u = {(unsigned short)NULL16, (unsigned short)NULL16};
+  auto canon = [&](unsigned w) {  // v < 0 ? NULL16 : min(v, tlen + 1), per half
+    const s2 c = __builtin_elementwise_min(as2(w), tlen1);
+    return asu(__builtin_bit_cast(s2, __builtin_elementwise_min(__builtin_bit_cast(us2, c), null_u)));
+  };
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  auto st = [&](int soff, int voff, const V& v) {
+    u32x2 w2;
+    w2[0] = v.w[0];
+    w2[1] = v.w[1];
+    __builtin_amdgcn_raw_buffer_store_b64(w2, rs, voff, soff, 0);
+  };
+  for (int cb = (colLoMin & ~(VEC - 1)) - MHALO * VEC + (NWAVES > 1 ? (int)(threadIdx.x >> 6) * MSTRIDE : 0); cb + MHALO * VEC <= colHiMax;
+       cb += MSTRIDE * NWAVES) {
+    const int c0 = cb + lane * VEC;
+    const int k0 = c0 + kmin;
+    const int voff = c0 * ESZ;
+    const bool interior = cb >= mp.int_lo && cb <= mp.int_hi;  // wave-uniform
+    // lanes that can matter: everything that lies inside some source's stored hull is within HALO lanes of the final hull
+    const bool load_on = c0 + (MHALO + 2) * VEC > colLoMin && c0 - (MHALO + 1) * VEC <= colHiMax;
+    // ---- all row loads of the pass, back to back
+    V qI1[E1], qD1[E1], qI2[E2], qD2[E2], tap[TMAX][NT];
+#pragma unroll
+    for (int j = 0; j < E1; ++j) { qI1[j] = V{}; qD1[j] = V{}; }
+#pragma unroll
+    for (int j = 0; j < E2; ++j) { qI2[j] = V{}; qD2[j] = V{}; }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+      for (int w = 0; w < NT; ++w) tap[t][w] = V{};
+    if (load_on) {
+#pragma unroll
+      for (int j = 0; j < E1; ++j) {
+        qI1[j] = buf_load_raw<OffT, 2>(rs, voff, row_off<false, OffT>(kp, dir, C_I1, s0 - E1 + 1 + j));
+        qD1[j] = buf_load_raw<OffT, 2>(rs, voff, row_off<false, OffT>(kp, dir, C_D1, s0 - E1 + 1 + j));
+      }
+      if (P2) {
+#pragma unroll
+        for (int j = 0; j < E2; ++j) {
+          qI2[j] = buf_load_raw<OffT, 2>(rs, voff, row_off<false, OffT>(kp, dir, C_I2, s0 - E2 + 1 + j));
+          qD2[j] = buf_load_raw<OffT, 2>(rs, voff, row_off<false, OffT>(kp, dir, C_D2, s0 - E2 + 1 + j));
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        if (t < Tn) {
+          tap[t][0] = buf_load_raw<OffT>(rs, voff, row_off<false, OffT>(kp, dir, C_M, s0 + 1 + t - pn.x));
+          tap[t][1] = buf_load_raw<OffT>(rs, voff, row_off<false, OffT>(kp, dir, C_M, s0 + 1 + t - pn.o1 - pn.e1));
+          if (P2) tap[t][NT - 1] = buf_load_raw<OffT>(rs, voff, row_off<false, OffT>(kp, dir, C_M, s0 + 1 + t - pn.o2 - pn.e2));
+        }
+      }
+    }
+    if (!interior) {  // edge windows: lane vectors outside the hull of a source's step hold nothing (or stale data)
+      auto lmask = [&](int r, V& v) {
+        const int alo = __builtin_amdgcn_readlane(mp.vlo, r), ahi = __builtin_amdgcn_readlane(mp.vhi, r);
+        const bool keep = c0 >= alo && c0 <= ahi;
+        v.w[0] = keep ? v.w[0] : nullw;
+        v.w[1] = keep ? v.w[1] : nullw;
+      };
+#pragma unroll
+      for (int j = 0; j < E1; ++j) { lmask(j, qI1[j]); lmask(E1 + j, qD1[j]); }
+      if (P2) {
+#pragma unroll
+        for (int j = 0; j < E2; ++j) { lmask(2 * E1 + j, qI2[j]); lmask(2 * E1 + E2 + j, qD2[j]); }
+      }
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        if (t < Tn) {
+#pragma unroll
+          for (int w = 0; w < NT; ++w) lmask(NS0 + NT * t + w, tap[t][w]);
+        }
+      }
+    }
+    const int hbase = plen + k0;
+    // ---- the steps
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+      if (t < Tn) {
+        const int score = s0 + 1 + t;
+        const bool lane_on = productive && c0 + VEC > mp.lo[t] - kmin && c0 <= mp.hi[t] - kmin;
+        const V cMx = tap[t][0], cO1 = tap[t][1];
+        const V rO1l = shift_from_left(cO1), rO1r = shift_from_right(cO1);
+        const V rI1 = shift_from_left(qI1[0]), rD1 = shift_from_right(qD1[0]);
+        V rO2l{}, rO2r{}, rI2{}, rD2{};
+        if (P2) {
+          rO2l = shift_from_left(tap[t][NT - 1]);
+          rO2r = shift_from_right(tap[t][NT - 1]);
+          rI2 = shift_from_left(qI2[0]);
+          rD2 = shift_from_right(qD2[0]);
+        }
+        V nI1, nD1, nI2{}, nD2{};
+        int32_t m[VEC];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const s2 ins1 = __builtin_elementwise_max(as2(rO1l.w[r]), as2(rI1.w[r])) + one;
+          const s2 del1 = __builtin_elementwise_max(as2(rO1r.w[r]), as2(rD1.w[r]));
+          s2 ins = ins1, del = del1;
+          nI1.w[r] = asu(ins1);
+          nD1.w[r] = asu(del1);
+          if (P2) {
+            const s2 ins2 = __builtin_elementwise_max(as2(rO2l.w[r]), as2(rI2.w[r])) + one;
+            const s2 del2 = __builtin_elementwise_max(as2(rO2r.w[r]), as2(rD2.w[r]));
+            ins = __builtin_elementwise_max(ins, ins2);
+            del = __builtin_elementwise_max(del, del2);
+            nI2.w[r] = asu(ins2);
+            nD2.w[r] = asu(del2);
+          }
+          const s2 mm2 = __builtin_elementwise_max(del, __builtin_elementwise_max(as2(cMx.w[r]) + one, ins));
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int mm = (int)mm2[e];
+            const int hmax = clamp_from_m1(hbase + 2 * r + e, tlen);
+            lane_oob |= lane_on && mm > hmax;
+            m[2 * r + e] = (mm > hmax || mm < 0 || !lane_on) ? OFF_NULL : mm;
+          }
+        }
+        extend_cells<OffT>(lds, cx, dir, k0, m, ext_iters);
+        int it_maxak = 0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          if (m[j] >= 0) it_maxak = max(it_maxak, 2 * m[j] - (k0 + j));
+        lane_maxak[t] = max(lane_maxak[t], it_maxak);
+        if (lane_on) buf_store_vec<OffT>(rs, voff, row_off<false, OffT>(kp, dir, C_M, score), m, tlen);
+        // the I/D rows of this score enter the register queues (oldest first)
+#pragma unroll
+        for (int j = 0; j + 1 < E1; ++j) { qI1[j] = qI1[j + 1]; qD1[j] = qD1[j + 1]; }
+        qI1[E1 - 1] = nI1;
+        qD1[E1 - 1] = nD1;
+        if (P2) {
+#pragma unroll
+          for (int j = 0; j + 1 < E2; ++j) { qI2[j] = qI2[j + 1]; qD2[j] = qD2[j + 1]; }
+          qI2[E2 - 1] = nI2;
+          qD2[E2 - 1] = nD2;
+        }
+      }
+    }
+    // ---- the pass's last e1 / e2 I/D rows (canonical form, whole lane vectors over their step's hull)
+    {
+      // queue entry j was produced by step Tn - E + j (Tn >= E); its lanes are those of that step's hull
+      auto step_lo = [&](int tj) {
+        int v = 1;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) v = (t == tj) ? mp.lo[t] : v;
+        return v;
+      };
+      auto step_hi = [&](int tj) {
+        int v = 0;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) v = (t == tj) ? mp.hi[t] : v;
+        return v;
+      };
+#pragma unroll
+      for (int j = 0; j < E1; ++j) {
+        const int tj = Tn - E1 + j;
+        const bool on = productive && c0 + VEC > step_lo(tj) - kmin && c0 <= step_hi(tj) - kmin;
+        if (on) {
+          V a, b;
+          a.w[0] = canon(qI1[j].w[0]); a.w[1] = canon(qI1[j].w[1]);
+          b.w[0] = canon(qD1[j].w[0]); b.w[1] = canon(qD1[j].w[1]);
+          st(row_off<false, OffT>(kp, dir, C_I1, s0 + 1 + tj), voff, a);
+          st(row_off<false, OffT>(kp, dir, C_D1, s0 + 1 + tj), voff, b);
+        }
+      }
+      if (P2) {
+#pragma unroll
+        for (int j = 0; j < E2; ++j) {
+          const int tj = Tn - E2 + j;
+          const bool on = productive && c0 + VEC > step_lo(tj) - kmin && c0 <= step_hi(tj) - kmin;
+          if (on) {
+            V a, b;
+            a.w[0] = canon(qI2[j].w[0]); a.w[1] = canon(qI2[j].w[1]);
+            b.w[0] = canon(qD2[j].w[0]); b.w[1] = canon(qD2[j].w[1]);
+            st(row_off<false, OffT>(kp, dir, C_I2, s0 + 1 + tj), voff, a);
+            st(row_off<false, OffT>(kp, dir, C_D2, s0 + 1 + tj), voff, b);
+          }
+        }
+      }
+    }
+  }
+  if (threadIdx.x == 0) sh.win_multi += (unsigned)((colHiMax - ((colLoMin & ~(VEC - 1)) - MHALO * VEC) - MHALO * VEC) / MSTRIDE + 1);
+  int cells = 0;
+  const bool woob = __any(lane_oob);
+#pragma unroll
+  for (int t = 0; t < TMAX; ++t) {
+    if (t < Tn) {
+      const int wmax = wave_max_i32(lane_maxak[t]);
+      if (lane == 0) atomicMax(&acc.maxak_t[t], wmax);
+      if (mp.lo[t] <= mp.hi[t]) cells += mp.hi[t] - mp.lo[t] + 1;
+    }
+  }
+  if (lane == 0 && woob) acc.oob = 1;
+  return cells;
+}
+
+// The far-apart phase as a function of its own (never inlined): inlined into the search loop, the ~110
+// live vector registers of a pass met everything else the kernel keeps alive and the compiler spilled
+// into the hot loop (even the buffer descriptor, which then has to be re-made uniform lane by lane).
+// One call per breakpoint search runs ALL of its multi-step passes -- both directions in lockstep, one
+// barrier per pass -- together with WFA2's phase-1 bookkeeping for the scores they cover, and hands the
+// search back to the step-by-step loop when (MP_MARGIN) the furthest points come within the safety margin
+// of meeting, (MP_DISCARD) a pass saw a value leave the matrix (that pass is not counted: its rows are
+// redone step by step) or (MP_MET) the furthest points met inside a pass: the I/D rows the overlap
+// search needs were then never written and the caller runs the search again step by step.
+// Inputs beyond the few scalars come from LDS (Shared::pctx), results go back through Shared::pres.
+typedef __attribute__((address_space(3))) Shared* lds_shared_ptr;
+typedef __attribute__((address_space(3))) unsigned char* lds_bytes_ptr;
+constexpr int MP_MARGIN = 0, MP_DISCARD = 1, MP_MET = 2, MP_ERROR = 3;
+template <bool P2, typename OffT, int E1, int E2>
+__device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned dyn_addr, int s0_v, int fmax_v, int rmax_v, int Tn_v, int pass_v) {
+  Shared& sh = *(Shared*)(lds_shared_ptr)(uintptr_t)sh_addr;
+  unsigned char* dyn_smem = (unsigned char*)(lds_bytes_ptr)(uintptr_t)dyn_addr;
+  const int Tn = uni(Tn_v);
+  int sc = uni(s0_v);  // both directions stand at the same score when the phase begins and after every pass
+  int fmax = uni(fmax_v), rmax = uni(rmax_v), pass = uni(pass_v);
+  const PassCtx& pc = sh.pctx;
+  KParams kp{};
+  kp.ring = uni(pc.ring);
+  kp.wcap = uni(pc.wcap);
+  kp.pen.x = uni(pc.x);
+  kp.pen.o1 = uni(pc.o1);
+  kp.pen.e1 = uni(pc.e1);
+  kp.pen.o2 = uni(pc.o2);
+  kp.pen.e2 = uni(pc.e2);
+  kp.pen.two_piece = P2 ? 1 : 0;
+  kp.pen.scope = max(kp.pen.x, max(kp.pen.o1 + kp.pen.e1, P2 ? kp.pen.o2 + kp.pen.e2 : 0)) + 1;
+  kp.lds_meta_bytes = uni(pc.lds_meta_bytes);
+  auto uni64 = [](unsigned long long v) { return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)v); };
+  SubCtx cx;
+  cx.plen = uni(pc.plen);
+  cx.tlen = uni(pc.tlen);
+  cx.kmin[0] = uni(pc.kmin[0]);
+  cx.kmin[1] = uni(pc.kmin[1]);
+  cx.wcols = uni(pc.wcols);
+  cx.seq_mode = uni(pc.seq_mode);
+  cx.p_w0 = uni(pc.p_w0);
+  cx.t_w0 = uni(pc.t_w0);
+  cx.p_bit = uni(pc.p_bit);
+  cx.t_bit = uni(pc.t_bit);
+  cx.P[0] = (gseq_t)(uintptr_t)uni64(pc.P[0]);
+  cx.P[1] = (gseq_t)(uintptr_t)uni64(pc.P[1]);
+  cx.T[0] = (gseq_t)(uintptr_t)uni64(pc.T[0]);
+  cx.T[1] = (gseq_t)(uintptr_t)uni64(pc.T[1]);
+  cx.Pw = nullptr;
+  cx.Tw = nullptr;
+  cx.pb_abs = cx.tb_abs = 0;
+  Lds<OffT> lds;
+  typedef typename MetaTraits<OffT>::Stored MetaStored;
+  lds.ring_meta = reinterpret_cast<MetaStored*>(dyn_smem);
+  lds.bi_A = reinterpret_cast<int*>(lds.ring_meta + 2 * NCOMP * kp.ring);
+  lds.bi_oob = lds.bi_A + 2 * kp.ring;
+  lds.firstk = lds.bi_oob + 2 * kp.ring;
+  lds.seq = reinterpret_cast<uint32_t*>(dyn_smem + kp.lds_meta_bytes);
+  lds.meta_log = nullptr;
+  const rsrc_t rs = make_rsrc((void*)(uintptr_t)uni64(pc.ring_mem), (size_t)uni64(pc.ring_bytes));
+  const int rmask = kp.ring - 1;
+  const int max_antidiagonal = cx.plen + cx.tlen - 1;
+  const int arun_start = fmax + rmax;
+  int arun0 = fmax, arun1 = rmax;  // max antidiagonal over every row computed so far, per direction
+  int nsteps = 0, npass = 0, why = MP_MARGIN;
+  unsigned long long cells = 0;
+  unsigned ext_iters = 0;
+  for (;;) {
+    // start keeping every I/D row well before the furthest points can meet: the margin is several times
+    // what the two searches advance while `scope` more rows (and one more pass) are computed
+    const int grow = nsteps > 0 ? (arun0 + arun1 - arun_start) / nsteps : 0;
+    const int margin = 256 + 2 * (kp.pen.scope + Tn) * max(grow, 8);
+    if (arun0 + arun1 >= max_antidiagonal - margin) { why = MP_MARGIN; break; }
+    const int aslot = pass % 3;
+    int nc0 = 0, nc1 = 0;
+    // (a real loop over the direction: one copy of the pass code; per-direction values are picked by
+    // selects, never by indexing a register array with the run-time `dir`)
+#pragma nounroll
+    for (int dir = 0; dir < 2; ++dir) {
+      MultiPlan mp;
+      plan_multi<P2, OffT, E1, E2>(kp, lds, cx, dir, sc, Tn, mp);
+      Acc& acc = dir ? sh.acc[aslot][1] : sh.acc[aslot][0];
+      const int nc = compute_rows_multi<P2, OffT, E1, E2>(kp, sh, lds, cx, rs, dir, sc, mp, acc, ext_iters);
+      if (dir) nc1 = nc; else nc0 = nc;
+    }
+    __syncthreads();
+    if (uni(sh.error)) { why = MP_ERROR; break; }
+    if (uni(sh.acc[aslot][0].oob) != 0 || uni(sh.acc[aslot][1].oob) != 0) { why = MP_DISCARD; break; }  // the pass assumed untrimmed rows
+    cells += (unsigned long long)(nc0 + nc1);
+    // the pass's rows become official one score at a time, in WFA2's phase-1 order (A.6): forward, test, reverse, test
+    bool met = false;
+    for (int t = 0; t < Tn; ++t) {
+      const int A0 = uni(sh.acc[aslot][0].maxak_t[t]), A1 = uni(sh.acc[aslot][1].maxak_t[t]);
+      const int slot = (sc + 1 + t) & rmask;
+      lds.bi_A[slot] = A0;
+      lds.bi_A[kp.ring + slot] = A1;
+      lds.bi_oob[slot] = 0;
+      lds.bi_oob[kp.ring + slot] = 0;
+      arun0 = max(arun0, A0);
+      arun1 = max(arun1, A1);
+      fmax = max(fmax, A0);
+      if (fmax + rmax >= max_antidiagonal) met = true;
+      rmax = max(rmax, A1);
+      if (fmax + rmax >= max_antidiagonal) met = true;
+    }
+    if (threadIdx.x == 0) { acc_reset(sh.acc[(pass + 2) % 3][0]); acc_reset(sh.acc[(pass + 2) % 3][1]); }
+    ++pass;
+    ++npass;
+    nsteps += Tn;
+    sc += Tn;
+    if (met) { why = MP_MET; break; }
+  }
+  __syncthreads();  // every thread is past its last look at the accumulators
+  if (threadIdx.x == 0) {
+    PhaseResult& pr = sh.pres;
+    pr.why = why;
+    pr.sc = sc;
+    pr.fmax = fmax;
+    pr.rmax = rmax;
+    pr.npass = npass;
+    pr.cells = cells;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { acc_reset(sh.acc[i][0]); acc_reset(sh.acc[i][1]); }  // whatever the caller's pass counter says next, its slot is clean
+  }
+  atomicAdd(&sh.ext_multi, (unsigned long long)ext_iters);
+  __syncthreads();
 }
 
 // Rare path (some value went out of bounds): find the trimmed hulls (A.3 "trim ends") by
@@ -955,7 +1432,7 @@ __device__ __forceinline__ int bt_fetch(const KParams& kp, const RowMeta* base_m
 enum { BT_I1_OPEN = 1, BT_I1_EXT = 2, BT_I2_OPEN = 3, BT_I2_EXT = 4, BT_D1_OPEN = 5, BT_D1_EXT = 6, BT_D2_OPEN = 7, BT_D2_EXT = 8, BT_M = 9 };
 
 template <bool P2, typename OffT>
-__device__ int base_align(const KParams& kp, Shared& sh, const Lds<OffT>& lds, SubCtx cx, void* hist_mem, rsrc_t hist_rs, uint32_t* events,
+__device__ __forceinline__ int base_align(const KParams& kp, Shared& sh, const Lds<OffT>& lds, SubCtx cx, void* hist_mem, rsrc_t hist_rs, uint32_t* events,
                           int cb, int ce, Emit& em, int& penalty_out, unsigned long long* lstats) {
   const DevPenalties& pn = kp.pen;
   const int tid = cold_tid(), lane = tid & 63;
@@ -1140,10 +1617,10 @@ __device__ int base_align(const KParams& kp, Shared& sh, const Lds<OffT>& lds, S
 // ---------------------------------------------------------------------------------------------
 // BiWFA breakpoint search (A.6)
 // ---------------------------------------------------------------------------------------------
-constexpr int BP_OK = 0, BP_END_REACHED = 100;
+constexpr int BP_OK = 0, BP_END_REACHED = 100, BP_RESTART = 101;
 
 template <bool P2, typename OffT>
-__device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& lds, const SubCtx& cx, void* ring_mem, rsrc_t ring_rs, int d0, int s0,
+__device__ __forceinline__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& lds, const SubCtx& cx, void* ring_mem, rsrc_t ring_rs, int d0, int s0,
                                 int s1, bool fwd, Breakpoint& bp, unsigned long long* lstats) {
   constexpr int VEC = OffTraits<OffT>::VEC;
   const DevPenalties& pn = kp.pen;
@@ -1349,8 +1826,8 @@ __device__ void bialign_overlap(const KParams& kp, Shared& sh, const Lds<OffT>& 
 }
 
 template <bool P2, typename OffT>
-__device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& lds, SubCtx cx, void* ring_mem, rsrc_t ring_rs, int cb, int ce,
-                               int score_remaining, int known_score, Breakpoint& bp, unsigned long long* lstats) {
+__device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& lds, SubCtx cx, void* ring_mem, rsrc_t ring_rs, int cb, int ce,
+                               int score_remaining, int known_score, bool force_single, Breakpoint& bp, unsigned long long* lstats) {
   const DevPenalties& pn = kp.pen;
   const int tid = cold_tid();
   const int plen = cx.plen, tlen = cx.tlen;
@@ -1371,6 +1848,25 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
     cx.kmin[1] = need - adj;
     cx.wcols = blo + bhi + 9 + adj + 2 * COL_PAD;
     if (cx.wcols > kp.wcap) return ST_CAPACITY;
+  }
+  const unsigned sh_addr = (unsigned)(uintptr_t)&sh, dyn_addr = (unsigned)(uintptr_t)lds.ring_meta;  // LDS addresses (low half of the flat ones)
+  if (sizeof(OffT) == 2 && !DIRSPLIT && tid == 0) {  // what multi_pass reads back (uniform; the barrier below publishes it)
+    PassCtx& pc = sh.pctx;
+    pc.ring_mem = (unsigned long long)(uintptr_t)ring_mem;
+    pc.ring_bytes = (unsigned long long)kp.ring_slot_stride;
+    pc.P[0] = (unsigned long long)(uintptr_t)cx.P[0];
+    pc.P[1] = (unsigned long long)(uintptr_t)cx.P[1];
+    pc.T[0] = (unsigned long long)(uintptr_t)cx.T[0];
+    pc.T[1] = (unsigned long long)(uintptr_t)cx.T[1];
+    pc.ring = kp.ring;
+    pc.wcap = kp.wcap;
+    pc.x = pn.x; pc.o1 = pn.o1; pc.e1 = pn.e1; pc.o2 = pn.o2; pc.e2 = pn.e2;
+    pc.lds_meta_bytes = kp.lds_meta_bytes;
+    pc.plen = plen; pc.tlen = tlen;
+    pc.kmin[0] = cx.kmin[0]; pc.kmin[1] = cx.kmin[1];
+    pc.wcols = cx.wcols;
+    pc.seq_mode = cx.seq_mode; pc.p_w0 = cx.p_w0; pc.t_w0 = cx.t_w0; pc.p_bit = cx.p_bit; pc.t_bit = cx.t_bit;
+    sh.ext_multi = 0;
   }
   // score-0 wavefronts (wavefront_unialign_init by begin component)
   for (int i = tid; i < 2 * NCOMP; i += WG) {
@@ -1405,7 +1901,7 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
   int fmax = uni(lds.bi_A[(0) * kp.ring + (0)]), rmax = uni(lds.bi_A[(1) * kp.ring + (0)]);
   bp.score = INT_MAX;
   unsigned ext_iters = 0;
-  unsigned long long cells = 0;
+  unsigned long long cells = 0, multi_cells = 0;
   int pass = 0;
   const long long max_steps = ((long long)pn.o1 + pn.o2 + 2LL * (pn.e1 + pn.e2) + pn.x) * ((long long)plen + tlen + 4) + 1024;
   long long steps = 0;
@@ -1421,6 +1917,17 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
   // of the search cannot change the result and is skipped.
   const bool known_optimum = known_score != INT_MAX;
   bool dirty[2] = {false, false};  // per direction: some row was trimmed, later steps mask element by element
+  // Multi-step passes (compute_rows_multi) while the searches are far apart; step by step -- every I/D
+  // row kept, as the overlap search needs them -- from a safe margin before they can meet.
+  constexpr bool MULTI_BUILD = sizeof(OffT) == 2 && !DIRSPLIT;
+  const int multi_T = (MULTI_BUILD && !force_single && plen + tlen > 1024) ? kp.multi_T : 0;  // 0: step by step throughout
+  bool deep_on = multi_T == 0;     // every step stores its I/D rows
+  int deep_since[2] = {deep_on ? 0 : INT_MAX, deep_on ? 0 : INT_MAX};  // first score from which all I/D rows are in HBM
+  // the overlap search of (d0, s0) against d1 reads the I/D rows of s0 and of scores s1 - scope + 1 .. s1
+  auto deep_ok = [&](int d0, int s0, int d1, int s1) {
+    const int lo_need = max(s1 - (pn.scope - 1), 1);
+    return (s0 == 0 || deep_since[d0] <= s0) && (s1 == 0 || deep_since[d1] <= lo_need);
+  };
   int phase = 1;
   // One loop for both phases (A.6).  Each iteration first makes sure the next forward and the next
   // reverse wavefront exist (one fused pass, one barrier), then runs WFA2's bookkeeping for it.
@@ -1431,6 +1938,38 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
       int plo[2] = {1, 1}, phi[2] = {0, 0};
       bool need[2];
       const unsigned long long tp0 = PROF_NOW();
+      if (MULTI_BUILD && !deep_on && (dirty[0] || dirty[1])) {
+        deep_on = true;
+        deep_since[0] = comp[0] + 1;
+        deep_since[1] = comp[1] + 1;
+      }
+      if (MULTI_BUILD && !deep_on && phase == 1 && comp[0] == sc[0] && comp[1] == sc[1] && sc[0] == sc[1] &&
+          sc[0] + 1 - (pn.scope - 1) >= 1) {
+        // ---- the far-apart phase: all multi-step passes of this search in one call (multi_phase)
+        if constexpr (MULTI_BUILD) {
+          if (P2 || pn.e1 == 1) multi_phase<P2, OffT, P2 ? 2 : 1, 1>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
+          else multi_phase<P2, OffT, 2, 1>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
+        }
+        const int why = uni(sh.pres.why);
+        if (why == MP_ERROR) { rc = uni(sh.error); break; }
+        if (why == MP_MET) { rc = BP_RESTART; break; }
+        sc[0] = sc[1] = comp[0] = comp[1] = uni(sh.pres.sc);
+        fmax = uni(sh.pres.fmax);
+        rmax = uni(sh.pres.rmax);
+        pass += uni(sh.pres.npass);
+        steps += (long long)uni(sh.pres.npass) * multi_T;
+        {
+          const unsigned long long c = ((unsigned long long)(unsigned)uni((int)(sh.pres.cells >> 32)) << 32) | (unsigned)uni((int)sh.pres.cells);
+          cells += c;
+          multi_cells += c;
+        }
+        deep_on = true;  // from here on step by step: every row of every component goes to HBM
+        deep_since[0] = comp[0] + 1;
+        deep_since[1] = comp[1] + 1;
+        last_fwd = false;
+        __syncthreads();  // (sh.pres may be rewritten by the next search only after everyone has read it)
+        continue;
+      } else {
 #pragma unroll
       for (int dir = 0; dir < 2; ++dir) {  // unrolled: every per-direction array keeps constant indices
         need[dir] = comp[dir] == sc[dir];
@@ -1468,6 +2007,7 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
         ++pass;
         PROF_ADD(STAT_T_BI_FINALIZE, tp2);
       }
+      }
     }
     if (phase == 1) {
       // phase 1: until the furthest points can collide
@@ -1483,6 +2023,7 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
       if (last_fwd) {
         const int min_sr = (sc[1] > pn.scope - 1) ? sc[1] - (pn.scope - 1) : 0;
         if (sc[0] + min_sr - gap_opening >= bp.score) break;
+        if (!deep_ok(0, sc[0], 1, sc[1])) { rc = BP_RESTART; break; }
         const unsigned long long to0 = PROF_NOW();
         bialign_overlap<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, 0, sc[0], sc[1], true, bp, lstats);
         PROF_ADD(STAT_T_OVERLAP, to0);
@@ -1491,6 +2032,7 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
       }
       const int min_sf = (sc[0] > pn.scope - 1) ? sc[0] - (pn.scope - 1) : 0;
       if (min_sf + sc[1] - gap_opening >= bp.score) break;
+      if (!deep_ok(1, sc[1], 0, sc[0])) { rc = BP_RESTART; break; }
       const unsigned long long to1 = PROF_NOW();
       bialign_overlap<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, 1, sc[1], sc[0], false, bp, lstats);
       PROF_ADD(STAT_T_OVERLAP, to1);
@@ -1505,9 +2047,11 @@ __device__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& l
     if (tid == 0) lstats[STAT_BREAKPOINTS] += 1;
   } else if (tid == 0) {
     lstats[STAT_CELLS] += cells;
+    lstats[STAT_MULTI_CELLS] += multi_cells;
     lstats[STAT_BREAKPOINTS] += 1;
   }
   atomicAdd(&lstats[STAT_EXTEND], (unsigned long long)ext_iters);
+  if (sizeof(OffT) == 2 && !DIRSPLIT && tid == 0) lstats[STAT_EXTEND] += sh.ext_multi;
   __syncthreads();  // LDS metadata is rewritten by the next sub-problem
   if (rc == BP_OK && bp.score == INT_MAX) rc = ST_INTERNAL;
   return rc;
@@ -1545,6 +2089,7 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
     if (tid == 0) {
       sh.cur_pair = (long long)atomicAdd(kp.work_counter, 1ULL);
       sh.error = 0;
+      sh.win_single = sh.win_multi = sh.win_base = 0;
     }
     __syncthreads();
     const long long pair = ((long long)uni((int)(sh.cur_pair >> 32)) << 32) | (unsigned)uni((int)sh.cur_pair);
@@ -1614,7 +2159,13 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
       bool do_base = t.score_remaining <= FALLBACK_MIN_SCORE;
       Breakpoint bp;
       if (!do_base) {
-        const int rc = find_breakpoint<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, t.cb, t.ce, t.score_remaining, t.known, bp, lstats);
+        int rc = BP_OK;
+        for (int attempt = 0; attempt < 2; ++attempt) {  // (one call site: the search stays inlined)
+          // second attempt: the searches met before the I/D history was being kept -- once more, step by step from the start
+          rc = find_breakpoint<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, t.cb, t.ce, t.score_remaining, t.known, attempt == 1, bp, lstats);
+          if (rc != BP_RESTART) break;
+          if (tid == 0) lstats[STAT_RESTARTS] += 1;
+        }
         if (rc == BP_END_REACHED) do_base = true;  // wavefront_bialign_exception -> plain WFA
         else if (rc != BP_OK) { status = rc; break; }
       }
@@ -1653,6 +2204,8 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
       r.t_end = em.cnt[0] + em.cnt[1] + em.cnt[2];
       kp.results[pair] = r;
       PROF_ADD(STAT_T_TOTAL, tt0);
+      lstats[STAT_WIN_SINGLE] += sh.win_single; lstats[STAT_WIN_MULTI] += sh.win_multi; lstats[STAT_WIN_BASE] += sh.win_base;
+      sh.win_single = sh.win_multi = sh.win_base = 0;
       if (status == ST_OK) {
         lstats[STAT_ALIGNED_BP] += (unsigned long long)plenT;
         lstats[STAT_PAIRS] += 1;

@@ -306,8 +306,15 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     if (pairs[i].q_idx < 0 || pairs[i].q_idx >= s.n || pairs[i].t_idx < 0 || pairs[i].t_idx >= s.n)
       return fail(AWV_ERR_ARG, "align_pairs: sequence index out of range");
   }
+  // multi-step passes (biwfa_device.hpp, compute_rows_multi): T steps per pass, T <= the nearest M source
+  // (so that every M row a pass reads was written by an earlier pass); instantiated for the I/D depths
+  // of the reference's presets (2-piece: e1 = 2 / e2 = 1; gap-affine: e = 1 or 2)
+  int multi_T = std::min(std::min(dp.x, dp.o1 + dp.e1), awv::TMAX);
+  if (dp.two_piece) multi_T = std::min(multi_T, dp.o2 + dp.e2);
+  if (dp.two_piece ? (dp.e1 != 2 || dp.e2 != 1) : (dp.e1 != 1 && dp.e1 != 2)) multi_T = 0;
+  if (multi_T < 2 || (e->cfg.flags & AWV_F_SINGLE_STEP)) multi_T = 0;
   int ring = 4;
-  while (ring < dp.scope + 2) ring *= 2;
+  while (ring < dp.scope + 2 + (multi_T > 0 ? multi_T - 1 : 0)) ring *= 2;
   const int64_t max_batch = e->cfg.max_batch_pairs > 0 ? e->cfg.max_batch_pairs : (int64_t)1 << 20;
   uint64_t max_arena = e->cfg.max_arena_bytes > 0 ? (uint64_t)e->cfg.max_arena_bytes : (uint64_t)8 << 30;
   if (const char* env = getenv("AWV_MAX_ARENA_MB")) max_arena = std::max<uint64_t>(1, (uint64_t)atoll(env)) << 20;  // experiment knob
@@ -541,6 +548,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       kp.npairs = m;
       kp.pen = dp;
       kp.ring = ring;
+      kp.multi_T = multi_T;
       kp.wcap = wc;
       kp.ring_mem = e->ring_mem.p;
       kp.ring_slot_stride = ring_stride;
@@ -724,6 +732,11 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   e->stats.pairs_completed = stat_tot[STAT_PAIRS];
   e->stats.scratch_bytes = e->ring_mem.bytes() + e->hist_mem.bytes() + e->ev_mem.bytes();
   for (int i = 0; i < 14; ++i) e->stats.prof[i] = stat_tot[STAT_T_TOTAL + i];
+  e->stats.restarts = stat_tot[STAT_RESTARTS];
+  e->stats.multi_cell_steps = stat_tot[STAT_MULTI_CELLS];
+  e->stats.windows[0] = stat_tot[STAT_WIN_SINGLE];
+  e->stats.windows[1] = stat_tot[STAT_WIN_MULTI];
+  e->stats.windows[2] = stat_tot[STAT_WIN_BASE];
   return AWV_OK;
 }
 

@@ -20,6 +20,7 @@ AWV_F_NO_PACKED_SEQ = 4
 AWV_F_ONE_WAVE = 8
 AWV_F_FOUR_WAVES = 16
 AWV_F_NO_ARENA_PROBE = 32
+AWV_F_SINGLE_STEP = 64
 
 #: every symbol include/allwave_hip.h declares
 EXPORTS = ("awv_abi_version", "awv_last_error", "awv_engine_create", "awv_engine_destroy",
@@ -54,7 +55,7 @@ class Stats(C.Structure):
                 ("launches", C.c_uint64), ("cell_steps", C.c_uint64), ("extend_steps", C.c_uint64),
                 ("n_breakpoints", C.c_uint64), ("n_base", C.c_uint64), ("overlap_scans", C.c_uint64),
                 ("aligned_bp", C.c_uint64), ("pairs_completed", C.c_uint64), ("scratch_bytes", C.c_uint64),
-                ("prof", C.c_uint64 * 14)]
+                ("prof", C.c_uint64 * 14), ("restarts", C.c_uint64), ("multi_cell_steps", C.c_uint64), ("windows", C.c_uint64 * 3)]
 
 
 PAIR_DTYPE = np.dtype([("q_idx", "<i4"), ("t_idx", "<i4"), ("q_revcomp", "<i4")])

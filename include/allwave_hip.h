@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define AWV_ABI_VERSION 1
+#define AWV_ABI_VERSION 2
 
 /* engine-level return codes (negative = failure; never aborts the process) */
 #define AWV_OK 0
@@ -79,6 +79,7 @@ typedef struct {
 #define AWV_F_NO_PACKED_SEQ 4  /* never stage 2-bit packed sequences in LDS (raw-byte probes from HBM only) */
 #define AWV_F_ONE_WAVE 8       /* always one wave per pair (default: four waves per pair for small batches, long sequences and unequal lengths, sixteen for a few very unequal pairs) */
 #define AWV_F_FOUR_WAVES 16    /* always four waves per pair */
+#define AWV_F_SINGLE_STEP 64    /* never use multi-step passes (every step stores all five rows; the round-1 kernel path) */
 #define AWV_F_NO_ARENA_PROBE 32 /* take the first ring-arena allocation as it comes (default: allocate up to four candidates and keep the
                                    one a 1 ms traffic probe finds fastest -- worth up to 6 % of kernel time, costs 1-3 s once per engine:
                                    for short-lived processes with little work) */
@@ -140,6 +141,9 @@ typedef struct {
    * [5] base-case steps, [6] backtrace, [7] CIGAR emission, [8] number of fused step passes,
    * [9..13] inside the step: row loads, DP arithmetic, extend, stores, reductions */
   uint64_t prof[14];
+  uint64_t restarts;          /* breakpoint searches run again step by step (multi-step passes met too early) */
+  uint64_t multi_cell_steps;  /* cells computed by multi-step passes (I/D rows kept in registers) */
+  uint64_t windows[3];        /* window iterations: [0] step-by-step (one step each), [1] multi-step passes (T steps each), [2] base case */
 } awv_stats;
 
 int awv_abi_version(void);
