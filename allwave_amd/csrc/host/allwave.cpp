@@ -278,10 +278,17 @@ AllPairIterator& AllPairIterator::with_orientation(Orientation o) { orientation_
 AllPairIterator& AllPairIterator::with_device(int device) { device_ = device; return *this; }
 void set_engine_flags(int flags) { g_engine_flags.store(flags); }
 AllPairIterator& AllPairIterator::with_shard(size_t rank, size_t world) {
+  // cost-balanced shards (planner::assign_shards_lpt): every process derives the same partition and
+  // keeps its own part, in list order; equal-cost lists (config 2 / 3) come out strided
   if (world <= 1) return *this;
+  std::vector<double> cost(pairs_.size());
+  for (size_t i = 0; i < pairs_.size(); ++i)
+    cost[i] = planner::predicted_pair_cost(sequences_[pairs_[i].first].seq.size(), sequences_[pairs_[i].second].seq.size(), params_);
+  const std::vector<uint32_t> shard = planner::assign_shards_lpt(cost, world);
   std::vector<std::pair<size_t, size_t>> mine;
   mine.reserve(pairs_.size() / world + 1);
-  for (size_t i = rank; i < pairs_.size(); i += world) mine.push_back(pairs_[i]);
+  for (size_t i = 0; i < pairs_.size(); ++i)
+    if (shard[i] == (uint32_t)rank) mine.push_back(pairs_[i]);
   pairs_.swap(mine);
   return *this;
 }
@@ -301,7 +308,7 @@ void AllPairIterator::run(const std::function<void(int64_t, int64_t, const awv_r
   std::vector<uint8_t> is_rev((size_t)n, 0);
   std::vector<awv_pair> ap((size_t)n);
   if (orientation_ == Orientation::Mash) {
-    is_rev = planner::orient_pairs_mash(sequences_, pairs_, 16);  // alignment.rs:69-94 (host threads)
+    is_rev = planner::orient_pairs_mash(sequences_, pairs_, planner::host_threads());  // alignment.rs:69-94 (host threads: the CLI's -t)
   } else if (orientation_ == Orientation::Wfa) {
     // determine_orientation_wfa (alignment.rs:157-175): align forward and reverse-complement with the
     // orientation params, compare #X+#I+#D; forward wins ties; a failed alignment counts as usize::MAX

@@ -107,7 +107,8 @@ int awh_all_pairs_paf_count(int n, const char* const* ids, const uint8_t* bytes,
   try {
     const std::vector<Sequence> seqs = make_seqs(n, ids, bytes, offs);
     AllPairIterator it(seqs, parse_scores(scores));
-    it.with_orientation(orientation == 0 ? Orientation::ForwardOnly : Orientation::Wfa).with_device(device);
+    it.with_orientation(orientation == 0 ? Orientation::ForwardOnly : orientation == 1 ? Orientation::Wfa : Orientation::Mash).with_device(device);
+    planner::set_host_threads(format_threads);
     uint64_t nb = 0, nl = 0;
     const auto t0 = std::chrono::steady_clock::now();
     it.for_each_paf_batch([&](const std::string& s) {
@@ -189,6 +190,21 @@ int awh_orient_mash(int n, const char* const* ids, const uint8_t* bytes, const u
   const auto r = planner::orient_pairs_mash(seqs, p, 8);
   memcpy(is_rev, r.data(), npairs);
   return 0;
+}
+
+// shard of every pair under the cost-balanced (LPT) partition AllPairIterator::with_shard uses; cost_out (nullable)
+// receives the predicted costs
+int awh_shard_pairs(const int64_t* pairs, size_t npairs, const int64_t* lens, const char* scores, size_t world, uint32_t* shard_out,
+                    double* cost_out, char* err, size_t cap) {
+  try {
+    const AlignmentParams p = parse_scores(scores);
+    std::vector<double> cost(npairs);
+    for (size_t i = 0; i < npairs; ++i) cost[i] = planner::predicted_pair_cost((size_t)lens[pairs[2 * i]], (size_t)lens[pairs[2 * i + 1]], p);
+    const std::vector<uint32_t> sh = planner::assign_shards_lpt(cost, world);
+    for (size_t i = 0; i < npairs; ++i) shard_out[i] = sh[i];
+    if (cost_out) for (size_t i = 0; i < npairs; ++i) cost_out[i] = cost[i];
+    return 0;
+  } catch (const std::exception& e) { set_err(err, cap, e.what()); return -1; }
 }
 
 void awh_free(void* p) { free(p); }

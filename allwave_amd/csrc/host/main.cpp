@@ -12,6 +12,7 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <stdexcept>
 
 #include "allwave.hpp"
 #include "planner.hpp"
@@ -170,6 +171,7 @@ int main(int argc, char** argv) {
   if (a.have_keep) filter(a.keep, true);
   if (a.have_exclude) filter(a.exclude, false);
 
+  planner::set_host_threads(a.threads);  // -t: sketching, mash orientation, PAF formatting
   if (a.mash_matrix) {  // main.rs:281-293
     const size_t k = strategy.kind == SparsificationStrategy::TreeSampling && strategy.kmer_size ? *strategy.kmer_size : 15;
     std::cout << planner::format_distance_matrix(sequences, planner::compute_distance_matrix(sequences, k, 1000));
@@ -203,9 +205,19 @@ int main(int argc, char** argv) {
     size_t done = 0;
     it.for_each_paf_batch([&](const std::string& chunk) {
       out.write(chunk.data(), (std::streamsize)chunk.size());
+      // a short write (disk full, closed pipe) must not pass for a complete PAF: the reference propagates
+      // the writer's error (main.rs:355 `writeln!(..)?`, joined at :451-453); throwing here makes the
+      // engine stop with AWV_ERR_SINK before any further batch
+      if (!out) throw std::runtime_error("write error on the PAF output");
       for (char c : chunk) done += c == '\n';
     }, a.threads);
     out.flush();
+    if (!out) die("write error on the PAF output (flush)", 1);
+    if (a.have_output) {
+      fout.close();
+      if (fout.fail()) die("write error on the PAF output (close)", 1);
+    }
+    if (done != total) die("internal: wrote " + std::to_string(done) + " of " + std::to_string(total) + " PAF lines", 1);
     if (!a.no_progress) {
       const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       char buf[160];

@@ -2,6 +2,8 @@
 #include "planner.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <queue>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -145,10 +147,14 @@ std::vector<uint8_t> orient_pairs_mash(const std::vector<Sequence>& seqs,
   return is_rev;
 }
 
+static std::atomic<int> g_host_threads{8};
+void set_host_threads(int threads) { g_host_threads.store(std::max(1, threads)); }
+int host_threads() { return g_host_threads.load(); }
+
 std::vector<std::vector<double>> compute_distance_matrix(const std::vector<Sequence>& seqs, size_t k, size_t sketch_size) {
   const size_t n = seqs.size();
   std::vector<std::vector<uint64_t>> sk(n);
-  parallel_for(n, 8, [&](size_t i) { sk[i] = sketch_sequence_canonical(seqs[i].seq, k, sketch_size); });
+  parallel_for(n, host_threads(), [&](size_t i) { sk[i] = sketch_sequence_canonical(seqs[i].seq, k, sketch_size); });
   std::vector<std::vector<double>> m(n, std::vector<double>(n, 0.0));
   for (size_t i = 0; i < n; ++i)
     for (size_t j = i + 1; j < n; ++j) m[i][j] = m[j][i] = mash_distance(jaccard(sk[i], sk[j]), k);
@@ -219,6 +225,45 @@ std::vector<std::pair<size_t, size_t>> extract_tree_pairs(const std::vector<Sequ
   std::sort(all.begin(), all.end());
   all.erase(std::unique(all.begin(), all.end()), all.end());
   return all;
+}
+
+
+double predicted_pair_cost(size_t qlen, size_t tlen, const AlignmentParams& params) {
+  const double lo = (double)std::min(qlen, tlen), g = (double)(qlen > tlen ? qlen - tlen : tlen - qlen);
+  double gap = 0;
+  if (g > 0) {
+    gap = params.gap_open + g * params.gap_extend;
+    if (params.gap2_open && params.gap2_extend) gap = std::min(gap, (double)*params.gap2_open + g * (double)*params.gap2_extend);
+  }
+  const double s = 0.06 * params.mismatch_penalty * lo + gap + 16.0;  // ~6 % of the bases pay a mismatch's worth
+  return s * s;
+}
+
+std::vector<uint32_t> assign_shards_lpt(const std::vector<double>& cost, size_t world) {
+  const size_t n = cost.size();
+  std::vector<uint32_t> shard(n, 0);
+  if (world <= 1 || n == 0) return shard;
+  bool uniform = true;
+  for (size_t i = 1; i < n && uniform; ++i) uniform = cost[i] == cost[0];
+  if (uniform) {  // LPT on equal costs is the strided shard
+    for (size_t i = 0; i < n; ++i) shard[i] = (uint32_t)(i % world);
+    return shard;
+  }
+  std::vector<uint32_t> order(n);
+  for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+  // min-heap of (load, rank)
+  typedef std::pair<double, uint32_t> LR;
+  std::priority_queue<LR, std::vector<LR>, std::greater<LR>> heap;
+  for (size_t r = 0; r < world; ++r) heap.push(LR(0.0, (uint32_t)r));
+  for (size_t k = 0; k < n; ++k) {
+    LR top = heap.top();
+    heap.pop();
+    shard[order[k]] = top.second;
+    top.first += cost[order[k]];
+    heap.push(top);
+  }
+  return shard;
 }
 
 }  // namespace planner

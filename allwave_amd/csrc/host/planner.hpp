@@ -34,6 +34,9 @@ double mash_distance(double jaccard, size_t k);                                 
 std::vector<uint8_t> orient_pairs_mash(const std::vector<Sequence>& seqs,
                                        const std::vector<std::pair<size_t, size_t>>& pairs, int threads);
 
+// host threads used by sketching / orientation when the caller does not say (the CLI's -t; default 8)
+void set_host_threads(int threads);
+int host_threads();
 std::vector<std::vector<double>> compute_distance_matrix(const std::vector<Sequence>& seqs, size_t k, size_t sketch_size);
 std::string format_distance_matrix(const std::vector<Sequence>& seqs, const std::vector<std::vector<double>>& m);
 
@@ -43,6 +46,17 @@ std::vector<std::pair<size_t, size_t>> apply_random_sparsification(std::vector<s
 std::vector<std::pair<size_t, size_t>> build_knn_graph(const std::vector<std::vector<double>>& d, size_t k, bool farthest);
 std::vector<std::pair<size_t, size_t>> extract_tree_pairs(const std::vector<Sequence>& seqs, size_t k_nearest,
                                                           size_t k_farthest, double random_fraction, size_t kmer_size);
+
+// ---- multi-GPU shards (what rayon's work stealing does for the reference, iterator.rs:222-233)
+// Predicted cost of one pair: cell-steps grow with the square of the optimal penalty, estimated from
+// the lengths -- a mismatch share proportional to the shorter sequence plus the gap a length
+// difference forces (priced with the penalties in use).  Only ratios matter.
+double predicted_pair_cost(size_t qlen, size_t tlen, const AlignmentParams& params);
+// Longest-processing-time-first assignment of pairs to `world` shards: pairs in descending predicted
+// cost (ties: list order), each to the currently lightest shard (ties: lowest rank).  Returns the
+// shard of every pair; deterministic, so every process derives the same partition.  A list whose
+// pairs all cost the same degenerates to the strided shard r, r + world, ...
+std::vector<uint32_t> assign_shards_lpt(const std::vector<double>& cost, size_t world);
 
 }  // namespace planner
 }  // namespace allwave

@@ -10,10 +10,19 @@ def env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def shard_pairs(pairs, rank, world):
-    """Strided shard of the pair list: rank r takes pairs r, r+world, ... (keeps per-rank cost even for a
-    row-major all-pairs list; every pair lands on exactly one rank)."""
-    return np.ascontiguousarray(pairs[rank::world])
+def shard_pairs(pairs, rank, world, lens=None, scores=None):
+    """This rank's part of the pair list (every pair lands on exactly one rank, list order kept).
+    With sequence lengths and scores: the cost-balanced LPT partition of the host library
+    (planner::assign_shards_lpt -- what `allwave_hip --shard R/N` uses), which keeps the predicted cost
+    of the shards even when pair costs span orders of magnitude (config 5).  Without: strided
+    (r, r + world, ...), which is what LPT gives for equal-cost lists (configs 2 and 3)."""
+    if world <= 1:
+        return np.ascontiguousarray(pairs)
+    if lens is None:
+        return np.ascontiguousarray(pairs[rank::world])
+    from . import host as H
+    shard, _ = H.shard_assignment(pairs, lens, ",".join(str(int(v)) for v in scores), world)
+    return np.ascontiguousarray(np.asarray(pairs)[shard == rank])
 
 
 def init(backend=None, device=None):
@@ -25,8 +34,9 @@ def init(backend=None, device=None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
-        torch.cuda.set_device(local_rank if device is None else device)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dev = local_rank if device is None else int(device)
+        torch.cuda.set_device(dev)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
     else:
         dist.init_process_group(backend=backend)
     return dist
@@ -54,6 +64,17 @@ def reduce_max_sum(dist, elapsed, sums):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     return float(t[0]), [float(x) for x in s]
+
+
+def gather_floats(dist, value):
+    """Every rank's `value`, in rank order, on every rank (per-rank kernel times of the bench line)."""
+    if dist is None:
+        return [float(value)]
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    out = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out, torch.tensor([float(value)], dtype=torch.float64, device=dev))
+    return [float(x) for x in out]
 
 
 def gather_bytes(dist, payload, local_rank=0):

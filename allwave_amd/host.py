@@ -197,6 +197,22 @@ def plan_pairs(ids, seqs, sparsification, exclude_self=True):
     return _pairs_out(out, n.value)
 
 
+def shard_assignment(pairs, lens, scores, world):
+    """Shard of every pair under the cost-balanced (LPT) partition AllPairIterator::with_shard uses
+    (planner::assign_shards_lpt) and the predicted per-pair costs.  pairs: int array [n, 2]; lens:
+    sequence lengths; scores: "m,x,o,e[,o2,e2]"."""
+    p = np.ascontiguousarray(np.asarray(pairs)[:, :2], dtype=np.int64)
+    ln = np.ascontiguousarray(lens, dtype=np.int64)
+    shard = np.zeros(len(p), dtype=np.uint32)
+    cost = np.zeros(len(p), dtype=np.float64)
+    e = _err()
+    rc = load().awh_shard_pairs(p.ctypes.data_as(C.c_void_p), C.c_size_t(len(p)), ln.ctypes.data_as(C.c_void_p), scores.encode(),
+                                C.c_size_t(int(world)), shard.ctypes.data_as(C.c_void_p), cost.ctypes.data_as(C.c_void_p), e, _CAP)
+    if rc != 0:
+        raise ValueError(e.value.decode())
+    return shard, cost
+
+
 def knn_graph(dist, k, farthest=False):
     d = np.ascontiguousarray(dist, dtype=np.float64)
     out = C.c_void_p()

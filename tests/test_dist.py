@@ -44,3 +44,46 @@ def test_two_ranks_equal_one(tmp_path):
     assert two["tmax"] == 1.5  # max over ranks of the per-rank timer
     # the gathered per-rank texts together are the single-process text
     assert two["lines"] == one["lines"] and len(one["lines"]) == one["n"]
+
+
+def test_bench_launches_its_own_ranks():
+    """A bare `python bench.py --gpus 2` (no WORLD_SIZE in the environment: the shape of the driver's
+    command) starts two ranks itself and relays rank 0's line; --launch-check runs the launcher, the
+    gloo rendezvous, the shard arithmetic and the reductions of the real run without a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, timeout=600)
+    line = json.loads([ln for ln in out.decode().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2
+    assert line["pairs_total"] == line["pairs_expected"] == 56 and line["pair_key_sum"] == line["pair_key_expected"]
+    assert line["per_rank_pairs"] == [28.0, 28.0] and line["elapsed_max"] == 0.002
+    # under a launcher, --gpus must agree with WORLD_SIZE
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                         env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), capture_output=True, timeout=120)
+    assert bad.returncode != 0 and b"WORLD_SIZE=3" in bad.stderr
+
+
+def test_cost_balanced_shards_config5():
+    """Config 5's pair list (512 prefixes of 1-50 kbp, -p tree:3:1:0.1): per-pair cost spans orders of
+    magnitude.  The LPT partition keeps max/mean predicted shard cost <= 1.05 for N = 8, every pair
+    lands on exactly one rank, and equal-cost lists come out strided."""
+    from allwave_amd import dist as D, host as H, synth
+    cfg = synth.CONFIGS["c5"]
+    data, offs, ids = synth.generate(cfg["nseq"], cfg["length"], cfg["d"], cfg["seed"], mixed_lengths=cfg["mixed_lengths"])
+    lens = (offs[1:] - offs[:-1]).astype(np.int64)
+    seqs = [bytes(data[offs[i]:offs[i + 1]]) for i in range(cfg["nseq"])]
+    plist = np.asarray(H.plan_pairs(ids, seqs, cfg["sparsify"]), dtype=np.int32)[:, :2]
+    shard, cost = H.shard_assignment(plist, lens, "0,5,8,2,24,1", 8)
+    assert cost.max() / cost.min() > 100  # the skew the partition has to absorb
+    loads = np.array([cost[shard == r].sum() for r in range(8)])
+    assert loads.max() / loads.mean() <= 1.05
+    parts = [D.shard_pairs(plist, r, 8, lens=lens, scores=cfg["scores"]) for r in range(8)]
+    assert sum(len(p) for p in parts) == len(plist)
+    assert {tuple(p) for part in parts for p in part} == {tuple(p) for p in plist}
+    for r in range(8):  # list order kept inside a shard
+        idx = np.flatnonzero(shard == r)
+        assert (parts[r] == plist[idx]).all()
+    # equal costs (config 2 / 3): LPT is the strided shard
+    eq = synth.all_pairs(12)
+    sh, _ = H.shard_assignment(eq, np.full(12, 10000), "0,5,8,2,24,1", 8)
+    assert (sh == np.arange(len(eq)) % 8).all()
