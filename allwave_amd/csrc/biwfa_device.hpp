@@ -78,7 +78,7 @@ enum { STAT_CELLS = 0, STAT_EXTEND, STAT_BREAKPOINTS, STAT_BASE, STAT_OVERLAP, S
        // cycle stamps (s_memtime, wave 0) -- only filled by the -DAWV_PROF diagnostic build
        STAT_T_TOTAL, STAT_T_BI_COMPUTE, STAT_T_BI_BARRIER, STAT_T_BI_FINALIZE, STAT_T_OVERLAP, STAT_T_BASE_STEPS,
        STAT_T_BACKTRACE, STAT_T_EMIT, STAT_N_PASSES,
-       STAT_T_CR_LOAD, STAT_T_CR_ALU, STAT_T_CR_EXTEND, STAT_T_CR_STORE, STAT_T_CR_REDUCE, STAT_RESTARTS, STAT_MULTI_CELLS, STAT_WIN_SINGLE, STAT_WIN_MULTI, STAT_WIN_BASE, STAT_N };
+       STAT_T_CR_LOAD, STAT_T_CR_ALU, STAT_T_CR_EXTEND, STAT_T_CR_STORE, STAT_T_CR_REDUCE, STAT_RESTARTS, STAT_MULTI_CELLS, STAT_WIN_SINGLE, STAT_WIN_MULTI, STAT_WIN_BASE, STAT_WIN_BASE_MULTI, STAT_N };
 
 #ifdef AWV_PROF
 #define PROF_DRAIN() __builtin_amdgcn_s_waitcnt(0)
@@ -130,7 +130,7 @@ struct KParams {
 struct RowMeta { int lo, hi; };
 constexpr int K_BIG = 1 << 28;  // an empty row is {K_BIG, -K_BIG}: min/max hulls ignore it for free
 #define ROW_EMPTY RowMeta{K_BIG, -K_BIG}
-struct Acc { int hull_lo[NCOMP]; int hull_hi[NCOMP]; int maxak; int oob; int maxak_t[8]; };  // maxak_t: per step of a multi-step pass
+struct Acc { int hull_lo[NCOMP]; int hull_hi[NCOMP]; int maxak; int oob; int maxak_t[8]; int reach; };  // maxak_t: per step of a multi-step pass
 struct Task { int pb, pe, tb, te, cb, ce, score_remaining, known; };  // known: the sub-problem's optimal score (INT_MAX at the top)
 struct Breakpoint { int score, sf, sr, kf, kr, off_f, off_r, comp; };
 
@@ -173,6 +173,9 @@ struct PassCtx {
   int lds_meta_bytes;
   int plen, tlen, kmin[2], wcols;
   int seq_mode, p_w0, t_w0, p_bit, t_bit;
+  // base case (base_phase): history arena instead of the ring, the metadata log, capacities, the end cell
+  unsigned long long meta_log;
+  int wb_cap, sb_cap, end_comp;
 };
 struct PhaseResult { int why, sc, fmax, rmax, npass; unsigned long long cells; };
 struct Shared {
@@ -180,7 +183,7 @@ struct Shared {
   PassCtx pctx;
   PhaseResult pres;
   unsigned long long ext_multi;  // extend probes counted by multi-step passes
-  unsigned int win_single, win_multi, win_base;  // windows processed (diagnostics)
+  unsigned int win_single, win_multi, win_base, win_base_multi;  // windows processed (diagnostics)
   int ext0[2];
   unsigned long long prof[5];
   long long cur_pair;
@@ -454,6 +457,7 @@ __device__ __forceinline__ void acc_reset(Acc& a) {
   a.oob = 0;
 #pragma unroll
   for (int t = 0; t < 8; ++t) a.maxak_t[t] = 0;
+  a.reach = 0;
 }
 
 struct StepPlan {  // uniform description of one compute-next call
@@ -568,63 +572,67 @@ __device__ __forceinline__ RawVec<int32_t> shift_from_right(const RawVec<int32_t
   return o;
 }
 
-// extend (A.4) of one lane vector's four M cells (m[j] < 0: NULL, left alone): the first probe (16 bases)
-// of all four cells is issued together (invalid cells probe offset 0, always readable), then the
-// longer runs continue in a loop
-template <typename OffT>
-__device__ __forceinline__ void extend_cells(const Lds<OffT>& lds, const SubCtx& cx, int dir, int k0, int32_t (&m)[4], unsigned& ext_iters) {
-  constexpr int VEC = 4;
+// extend (A.4) of N = 4 * steps M cells of one lane (cell i lies on diagonal k0 + i % 4; m[i] < 0: NULL, left
+// alone): the first probe (16 bases) of all N cells is issued together -- one LDS round trip for the lot,
+// invalid cells probe offset 0, always readable -- then the few longer runs continue in a loop each
+template <typename OffT, int N>
+__device__ __forceinline__ void extend_cells_n(const Lds<OffT>& lds, const SubCtx& cx, int dir, int k0, int32_t (&m)[N], unsigned& ext_iters) {
+  static_assert(N % 4 == 0 && N <= 32, "whole lane vectors");
   const gseq_t Pp = dir ? cx.P[1] : cx.P[0];  // (selects: `dir` may be a run-time value, SubCtx lives in registers)
   const gseq_t Tp = dir ? cx.T[1] : cx.T[0];
   const int plen = cx.plen, tlen = cx.tlen;
-  int rr[VEC], vv[VEC], hh[VEC];
-  uint64_t xx[VEC];
+  int rr[N], vv[N], hh[N];
   const bool packed = cx.seq_mode != 0;
   const uint32_t* seq = lds.seq;
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) {
+  for (int j = 0; j < N; ++j) {
     const bool ok = m[j] >= 0;
-    vv[j] = ok ? m[j] - (k0 + j) : 0;
+    vv[j] = ok ? m[j] - (k0 + (j & 3)) : 0;
     hh[j] = ok ? m[j] : 0;
     rr[j] = ok ? min(plen - vv[j], tlen - hh[j]) : 0;
   }
-  // uniform branches hoisted out of the per-cell code so the four probes stay back to back
-  int cont = 0;
+  // uniform branches hoisted out of the per-cell code so the probes stay back to back
+  unsigned cont = 0;
   if (packed) {
-    int nn[VEC];
+    int nn[N];
     if (dir == 0) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) nn[j] = packed_first_count<0>(seq, cx, vv[j], hh[j]);
+      for (int j = 0; j < N; ++j) nn[j] = packed_first_count<0>(seq, cx, vv[j], hh[j]);
     } else {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) nn[j] = packed_first_count<1>(seq, cx, vv[j], hh[j]);
+      for (int j = 0; j < N; ++j) nn[j] = packed_first_count<1>(seq, cx, vv[j], hh[j]);
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      cont |= (nn[j] == PROBE_FIRST && rr[j] > PROBE_FIRST) ? (1 << j) : 0;
+    for (int j = 0; j < N; ++j) {
+      cont |= (nn[j] == PROBE_FIRST && rr[j] > PROBE_FIRST) ? (1u << j) : 0u;
       m[j] += min(nn[j], rr[j]);  // rr == 0 for NULL cells: unchanged
     }
   } else {
+    uint64_t xx[N];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) xx[j] = ld64u(Pp + (unsigned)vv[j]) ^ ld64u(Tp + (unsigned)hh[j]);
+    for (int j = 0; j < N; ++j) xx[j] = ld64u(Pp + (unsigned)vv[j]) ^ ld64u(Tp + (unsigned)hh[j]);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
+    for (int j = 0; j < N; ++j) {
       int n = xx[j] ? (int)(__builtin_ctzll(xx[j]) >> 3) : PROBE_BYTES;
-      cont |= (n == PROBE_BYTES && rr[j] > PROBE_BYTES) ? (1 << j) : 0;
+      cont |= (n == PROBE_BYTES && rr[j] > PROBE_BYTES) ? (1u << j) : 0u;
       m[j] += min(n, rr[j]);
     }
   }
-  ext_iters += VEC;
+  ext_iters += N;
   if (cont) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      if (cont & (1 << j)) {
-        const int v = m[j] - (k0 + j), h = m[j];
+    for (int j = 0; j < N; ++j) {
+      if (cont & (1u << j)) {
+        const int v = m[j] - (k0 + (j & 3)), h = m[j];
         if (packed) m[j] += dir == 0 ? extend_lcp_packed<0>(seq, cx, v, h, ext_iters) : extend_lcp_packed<1>(seq, cx, v, h, ext_iters);
         else m[j] += extend_lcp(Pp, Tp, v, h, plen, tlen, ext_iters);
       }
     }
   }
+}
+template <typename OffT>
+__device__ __forceinline__ void extend_cells(const Lds<OffT>& lds, const SubCtx& cx, int dir, int k0, int32_t (&m)[4], unsigned& ext_iters) {
+  extend_cells_n<OffT, 4>(lds, cx, dir, k0, m, ext_iters);
 }
 
 // One compute-next + extend step of one direction (A.3 + A.4).  Every lane owns VEC consecutive
@@ -911,6 +919,10 @@ constexpr int TMAX = AWV_TMAX;
 constexpr int MHALO = (TMAX + 3) / 4;       // unproductive lanes on either side of a window
 constexpr int MPROD = 64 - 2 * MHALO;       // productive lanes
 constexpr int MSTRIDE = MPROD * 4;          // new columns per window
+#ifndef AWV_MEXT_GROUP
+#define AWV_MEXT_GROUP 1
+#endif
+constexpr int MEXT_GROUP = AWV_MEXT_GROUP;  // steps whose extension probes are issued together
 static_assert(TMAX >= 2 && TMAX <= 8, "pass length");
 
 struct MultiPlan {
@@ -919,6 +931,7 @@ struct MultiPlan {
   int lo_min, hi_max;        // union of the step hulls
   int vlo, vhi;              // VGPR: lane r = source r's stored hull as lane-aligned columns (empty: BIG / -BIG)
   int int_lo, int_hi;        // window origins whose 64 lane vectors lie inside every source's stored hull
+  int end_comp, end_col;     // base case: component and column of the end cell (k = tlen - plen); end_col < 0: no termination test
 };
 
 // source r of a pass that starts after score s0: which component at which score
@@ -937,7 +950,7 @@ __device__ __forceinline__ void multi_source(const DevPenalties& pn, int s0, int
   }
 }
 
-template <bool P2, typename OffT, int E1, int E2>
+template <bool P2, typename OffT, int E1, int E2, bool BASE>
 __device__ __forceinline__ void plan_multi(const KParams& kp, const Lds<OffT>& lds, const SubCtx& cx, int dir, int s0, int Tn, MultiPlan& mp) {
   constexpr int NS0 = 2 * E1 + (P2 ? 2 * E2 : 0);
   constexpr int NT = P2 ? 3 : 2;
@@ -946,13 +959,15 @@ __device__ __forceinline__ void plan_multi(const KParams& kp, const Lds<OffT>& l
   mp.Tn = Tn;
   mp.lo_min = K_BIG;
   mp.hi_max = -K_BIG;
+  mp.end_comp = C_M;
+  mp.end_col = -1;
 #pragma unroll
   for (int t = 0; t < TMAX; ++t) {
     mp.lo[t] = 1;
     mp.hi[t] = 0;
     if (t < Tn) {  // (uniform) the predicted metadata of step t is in LDS before step t + 1 is planned
       StepPlan pl;
-      plan_step<P2, false, OffT>(kp, lds, dir, s0 + 1 + t, pl);
+      plan_step<P2, BASE, OffT>(kp, lds, dir, s0 + 1 + t, pl);
       mp.lo[t] = pl.lo;
       mp.hi[t] = pl.hi;
       if (pl.lo <= pl.hi) {
@@ -961,14 +976,17 @@ __device__ __forceinline__ void plan_multi(const KParams& kp, const Lds<OffT>& l
       }
     }
   }
-  // every source row's stored extent = the hull of the step that wrote it (its M row's metadata; all
-  // source scores are >= 1 here, so no score-0 special case), fetched by lane r in one LDS round trip
+  // every source row's stored extent = the hull of the step that wrote it (its M row's metadata), fetched by
+  // lane r in one LDS round trip.  Score 0 is special -- the search's origin: one cell in the begin
+  // component's row, nothing stored for the others -- so there the component's own range counts; rows
+  // of negative scores do not exist.
   const int lane = threadIdx.x & 63;
   const int ns = NS0 + NT * Tn;
   int comp, score;
   multi_source<P2, E1, E2>(pn, s0, lane, comp, score);
   RowMeta h = ROW_EMPTY;
-  if (lane < ns) h = meta_load(&lds.ring_meta[(dir * NCOMP + C_M) * kp.ring + (score & (kp.ring - 1))]);
+  if (lane < ns && score >= 0)
+    h = meta_load(&lds.ring_meta[(dir * NCOMP + (score == 0 ? comp : C_M)) * kp.ring + (score & (kp.ring - 1))]);
   const bool empty = h.lo > h.hi;
   mp.vlo = empty ? K_BIG : ((h.lo - kmin) & ~3);
   mp.vhi = empty ? -K_BIG : ((h.hi - kmin) | 3);
@@ -977,9 +995,12 @@ __device__ __forceinline__ void plan_multi(const KParams& kp, const Lds<OffT>& l
 }
 
 // One pass: Tn steps of one direction over all windows of the rows.  Returns the number of cells.
-template <bool P2, typename OffT, int E1, int E2>
+// BASE: the base case's plain WFA (rows indexed by score in the history arena; every step also stores its I/D
+// rows -- the backtrace reads them -- and tells whether the end cell has been reached).
+template <bool P2, typename OffT, int E1, int E2, bool BASE>
 __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh, const Lds<OffT>& lds, const SubCtx& cx, rsrc_t rs,
                                                   int dir, int s0, const MultiPlan& mp, Acc& acc, unsigned& ext_iters) {
+  constexpr bool DEEP = BASE;  // every step's I/D rows go to memory
   static_assert(sizeof(OffT) == 2, "multi-step windows: 16-bit rows");
   static_assert(E1 >= 1 && E1 <= 2 && E2 >= 1 && E2 <= 2, "register-resident I/D depth");
   constexpr int NWAVES = WG / 64;
@@ -1004,6 +1025,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
 #pragma unroll
   for (int t = 0; t < TMAX; ++t) lane_maxak[t] = 0;
   bool lane_oob = false;
+  unsigned reach_mask = 0;  // BASE: bit t = the end cell has been reached at step t (uniform)
   typedef short s2 __attribute__((ext_vector_type(2)));
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
   auto as2 = [](unsigned w) { return __builtin_bit_cast(s2, w); };
@@ -1032,6 +1054,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
     // lanes that can matter: everything that lies inside some source's stored hull is within HALO lanes of the final hull
     const bool load_on = c0 + (MHALO + 2) * VEC > colLoMin && c0 - (MHALO + 1) * VEC <= colHiMax;
     // ---- all row loads of the pass, back to back
+    const unsigned long long tm0 = PROF_NOW();
     V qI1[E1], qD1[E1], qI2[E2], qD2[E2], tap[TMAX][NT];
 #pragma unroll
     for (int j = 0; j < E1; ++j) { qI1[j] = V{}; qD1[j] = V{}; }
@@ -1044,22 +1067,22 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
     if (load_on) {
 #pragma unroll
       for (int j = 0; j < E1; ++j) {
-        qI1[j] = buf_load_raw<OffT, 2>(rs, voff, row_off<false, OffT>(kp, dir, C_I1, s0 - E1 + 1 + j));
-        qD1[j] = buf_load_raw<OffT, 2>(rs, voff, row_off<false, OffT>(kp, dir, C_D1, s0 - E1 + 1 + j));
+        qI1[j] = buf_load_raw<OffT, 2>(rs, voff, row_off<BASE, OffT>(kp, dir, C_I1, s0 - E1 + 1 + j));
+        qD1[j] = buf_load_raw<OffT, 2>(rs, voff, row_off<BASE, OffT>(kp, dir, C_D1, s0 - E1 + 1 + j));
       }
       if (P2) {
 #pragma unroll
         for (int j = 0; j < E2; ++j) {
-          qI2[j] = buf_load_raw<OffT, 2>(rs, voff, row_off<false, OffT>(kp, dir, C_I2, s0 - E2 + 1 + j));
-          qD2[j] = buf_load_raw<OffT, 2>(rs, voff, row_off<false, OffT>(kp, dir, C_D2, s0 - E2 + 1 + j));
+          qI2[j] = buf_load_raw<OffT, 2>(rs, voff, row_off<BASE, OffT>(kp, dir, C_I2, s0 - E2 + 1 + j));
+          qD2[j] = buf_load_raw<OffT, 2>(rs, voff, row_off<BASE, OffT>(kp, dir, C_D2, s0 - E2 + 1 + j));
         }
       }
 #pragma unroll
       for (int t = 0; t < TMAX; ++t) {
         if (t < Tn) {
-          tap[t][0] = buf_load_raw<OffT>(rs, voff, row_off<false, OffT>(kp, dir, C_M, s0 + 1 + t - pn.x));
-          tap[t][1] = buf_load_raw<OffT>(rs, voff, row_off<false, OffT>(kp, dir, C_M, s0 + 1 + t - pn.o1 - pn.e1));
-          if (P2) tap[t][NT - 1] = buf_load_raw<OffT>(rs, voff, row_off<false, OffT>(kp, dir, C_M, s0 + 1 + t - pn.o2 - pn.e2));
+          tap[t][0] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, s0 + 1 + t - pn.x));
+          tap[t][1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, s0 + 1 + t - pn.o1 - pn.e1));
+          if (P2) tap[t][NT - 1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, s0 + 1 + t - pn.o2 - pn.e2));
         }
       }
     }
@@ -1085,11 +1108,19 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
       }
     }
     const int hbase = plen + k0;
-    // ---- the steps
+    PROF_DRAIN();
+    PROF_ADD_L(STAT_T_CR_LOAD, tm0);
+    // ---- the steps, in three sweeps.  Within a pass a step's recurrences need the earlier steps' I/D values and
+    // M rows of EARLIER passes only -- never the extended M values of this pass -- so all the DP arithmetic
+    // goes first, then the extension probes of several steps' cells are issued together (one LDS round trip
+    // per group instead of one per step), then the M rows are stored.
+    int32_t mall[TMAX * VEC];  // step t's four M cells: before extension after sweep 1, final after sweep 2
+    const unsigned long long tm1 = PROF_NOW();
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) mall[t * VEC + j] = OFF_NULL;
       if (t < Tn) {
-        const int score = s0 + 1 + t;
         const bool lane_on = productive && c0 + VEC > mp.lo[t] - kmin && c0 <= mp.hi[t] - kmin;
         const V cMx = tap[t][0], cO1 = tap[t][1];
         const V rO1l = shift_from_left(cO1), rO1r = shift_from_right(cO1);
@@ -1102,7 +1133,6 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           rD2 = shift_from_right(qD2[0]);
         }
         V nI1, nD1, nI2{}, nD2{};
-        int32_t m[VEC];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const s2 ins1 = __builtin_elementwise_max(as2(rO1l.w[r]), as2(rI1.w[r])) + one;
@@ -1124,16 +1154,30 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             const int mm = (int)mm2[e];
             const int hmax = clamp_from_m1(hbase + 2 * r + e, tlen);
             lane_oob |= lane_on && mm > hmax;
-            m[2 * r + e] = (mm > hmax || mm < 0 || !lane_on) ? OFF_NULL : mm;
+            mall[t * VEC + 2 * r + e] = (mm > hmax || mm < 0 || !lane_on) ? OFF_NULL : mm;
           }
         }
-        extend_cells<OffT>(lds, cx, dir, k0, m, ext_iters);
-        int it_maxak = 0;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j)
-          if (m[j] >= 0) it_maxak = max(it_maxak, 2 * m[j] - (k0 + j));
-        lane_maxak[t] = max(lane_maxak[t], it_maxak);
-        if (lane_on) buf_store_vec<OffT>(rs, voff, row_off<false, OffT>(kp, dir, C_M, score), m, tlen);
+        if (DEEP && lane_on) {  // this score's I/D rows (canonical form), whole lane vectors over the step's hull
+          V a, b;
+          a.w[0] = canon(nI1.w[0]); a.w[1] = canon(nI1.w[1]);
+          b.w[0] = canon(nD1.w[0]); b.w[1] = canon(nD1.w[1]);
+          st(row_off<BASE, OffT>(kp, dir, C_I1, s0 + 1 + t), voff, a);
+          st(row_off<BASE, OffT>(kp, dir, C_D1, s0 + 1 + t), voff, b);
+          if (P2) {
+            a.w[0] = canon(nI2.w[0]); a.w[1] = canon(nI2.w[1]);
+            b.w[0] = canon(nD2.w[0]); b.w[1] = canon(nD2.w[1]);
+            st(row_off<BASE, OffT>(kp, dir, C_I2, s0 + 1 + t), voff, a);
+            st(row_off<BASE, OffT>(kp, dir, C_D2, s0 + 1 + t), voff, b);
+          }
+        }
+        if (BASE && mp.end_comp != C_M) {  // end cell in an indel component: has its offset reached the text end?
+          const V& ev = mp.end_comp == C_I1 ? nI1 : mp.end_comp == C_D1 ? nD1 : mp.end_comp == C_I2 ? nI2 : nD2;
+          const int je = mp.end_col - c0;  // element of this lane's vector, if it holds the end column
+          const bool mine = lane_on && je >= 0 && je < VEC;
+          const unsigned w = (je & 2) ? ev.w[1] : ev.w[0];
+          const int val = (je & 1) ? ((int)w >> 16) : (((int)w << 16) >> 16);
+          if (__any(mine && val >= tlen)) reach_mask |= 1u << t;
+        }
         // the I/D rows of this score enter the register queues (oldest first)
 #pragma unroll
         for (int j = 0; j + 1 < E1; ++j) { qI1[j] = qI1[j + 1]; qD1[j] = qD1[j + 1]; }
@@ -1147,8 +1191,62 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
         }
       }
     }
+    PROF_DRAIN();
+    PROF_ADD_L(STAT_T_CR_ALU, tm1);
+    const unsigned long long tm2 = PROF_NOW();
+    {  // (steps beyond Tn hold NULL cells: they probe offset 0 and stay NULL)
+      constexpr int G = MEXT_GROUP;  // steps whose probes are in flight together
+#pragma unroll
+      for (int g = 0; g < TMAX; g += G) {
+        if (g < Tn) {
+          constexpr int NG = G * VEC;
+          if (g + G <= TMAX) {
+            int32_t mg[NG];
+#pragma unroll
+            for (int i = 0; i < NG; ++i) mg[i] = mall[g * VEC + i];
+            extend_cells_n<OffT, NG>(lds, cx, dir, k0, mg, ext_iters);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) mall[g * VEC + i] = mg[i];
+          } else {  // the last, shorter group
+            constexpr int NR = (TMAX % G) * VEC > 0 ? (TMAX % G) * VEC : VEC;
+            int32_t mg[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) mg[i] = mall[g * VEC + i];
+            extend_cells_n<OffT, NR>(lds, cx, dir, k0, mg, ext_iters);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) mall[g * VEC + i] = mg[i];
+          }
+        }
+      }
+    }
+    PROF_DRAIN();
+    PROF_ADD_L(STAT_T_CR_EXTEND, tm2);
+    const unsigned long long tm3 = PROF_NOW();
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+      if (t < Tn) {
+        const bool lane_on = productive && c0 + VEC > mp.lo[t] - kmin && c0 <= mp.hi[t] - kmin;
+        int32_t m[VEC];
+        int it_maxak = 0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          m[j] = mall[t * VEC + j];
+          if (m[j] >= 0) it_maxak = max(it_maxak, 2 * m[j] - (k0 + j));
+        }
+        lane_maxak[t] = max(lane_maxak[t], it_maxak);
+        if (lane_on) buf_store_vec<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, s0 + 1 + t), m, tlen);
+        if (BASE && mp.end_comp == C_M) {
+          const int je = mp.end_col - c0;
+          const bool mine = lane_on && je >= 0 && je < VEC;
+          const int val = je == 0 ? m[0] : je == 1 ? m[1] : je == 2 ? m[2] : m[3];
+          if (__any(mine && val >= tlen)) reach_mask |= 1u << t;
+        }
+      }
+    }
+    PROF_DRAIN();
+    PROF_ADD_L(STAT_T_CR_STORE, tm3);
     // ---- the pass's last e1 / e2 I/D rows (canonical form, whole lane vectors over their step's hull)
-    {
+    if (!DEEP) {
       // queue entry j was produced by step Tn - E + j (Tn >= E); its lanes are those of that step's hull
       auto step_lo = [&](int tj) {
         int v = 1;
@@ -1170,8 +1268,8 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           V a, b;
           a.w[0] = canon(qI1[j].w[0]); a.w[1] = canon(qI1[j].w[1]);
           b.w[0] = canon(qD1[j].w[0]); b.w[1] = canon(qD1[j].w[1]);
-          st(row_off<false, OffT>(kp, dir, C_I1, s0 + 1 + tj), voff, a);
-          st(row_off<false, OffT>(kp, dir, C_D1, s0 + 1 + tj), voff, b);
+          st(row_off<BASE, OffT>(kp, dir, C_I1, s0 + 1 + tj), voff, a);
+          st(row_off<BASE, OffT>(kp, dir, C_D1, s0 + 1 + tj), voff, b);
         }
       }
       if (P2) {
@@ -1183,14 +1281,14 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             V a, b;
             a.w[0] = canon(qI2[j].w[0]); a.w[1] = canon(qI2[j].w[1]);
             b.w[0] = canon(qD2[j].w[0]); b.w[1] = canon(qD2[j].w[1]);
-            st(row_off<false, OffT>(kp, dir, C_I2, s0 + 1 + tj), voff, a);
-            st(row_off<false, OffT>(kp, dir, C_D2, s0 + 1 + tj), voff, b);
+            st(row_off<BASE, OffT>(kp, dir, C_I2, s0 + 1 + tj), voff, a);
+            st(row_off<BASE, OffT>(kp, dir, C_D2, s0 + 1 + tj), voff, b);
           }
         }
       }
     }
   }
-  if (threadIdx.x == 0) sh.win_multi += (unsigned)((colHiMax - ((colLoMin & ~(VEC - 1)) - MHALO * VEC) - MHALO * VEC) / MSTRIDE + 1);
+  if (threadIdx.x == 0) (BASE ? sh.win_base_multi : sh.win_multi) += (unsigned)((colHiMax - ((colLoMin & ~(VEC - 1)) - MHALO * VEC) - MHALO * VEC) / MSTRIDE + 1);
   int cells = 0;
   const bool woob = __any(lane_oob);
 #pragma unroll
@@ -1202,6 +1300,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
     }
   }
   if (lane == 0 && woob) acc.oob = 1;
+  if (BASE && lane == 0 && reach_mask) atomicOr(&acc.reach, (int)reach_mask);
   return cells;
 }
 
@@ -1285,9 +1384,9 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
 #pragma nounroll
     for (int dir = 0; dir < 2; ++dir) {
       MultiPlan mp;
-      plan_multi<P2, OffT, E1, E2>(kp, lds, cx, dir, sc, Tn, mp);
+      plan_multi<P2, OffT, E1, E2, false>(kp, lds, cx, dir, sc, Tn, mp);
       Acc& acc = dir ? sh.acc[aslot][1] : sh.acc[aslot][0];
-      const int nc = compute_rows_multi<P2, OffT, E1, E2>(kp, sh, lds, cx, rs, dir, sc, mp, acc, ext_iters);
+      const int nc = compute_rows_multi<P2, OffT, E1, E2, false>(kp, sh, lds, cx, rs, dir, sc, mp, acc, ext_iters);
       if (dir) nc1 = nc; else nc0 = nc;
     }
     __syncthreads();
@@ -1328,6 +1427,102 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
     pr.cells = cells;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { acc_reset(sh.acc[i][0]); acc_reset(sh.acc[i][1]); }  // whatever the caller's pass counter says next, its slot is clean
+  }
+  atomicAdd(&sh.ext_multi, (unsigned long long)ext_iters);
+  __syncthreads();
+}
+
+// The base case's counterpart of multi_phase: plain WFA over the history arena in multi-step passes
+// (one memory round trip per T scores instead of one per score -- the base case's rows are a window
+// or two wide, so it is bound by exactly that latency), until the end cell is reached (MP_MET: pres.sc
+// is the final score), a pass sees a value leave the matrix (MP_DISCARD: continue step by step after
+// pres.sc) or the history's score capacity comes near (MP_MARGIN: likewise).
+template <bool P2, typename OffT, int E1, int E2>
+__device__ __attribute__((noinline)) void base_phase(unsigned sh_addr, unsigned dyn_addr, int s0_v, int Tn_v, int pass_v) {
+  Shared& sh = *(Shared*)(lds_shared_ptr)(uintptr_t)sh_addr;
+  unsigned char* dyn_smem = (unsigned char*)(lds_bytes_ptr)(uintptr_t)dyn_addr;
+  const int Tn = uni(Tn_v);
+  int sc = uni(s0_v), pass = uni(pass_v);
+  const PassCtx& pc = sh.pctx;
+  KParams kp{};
+  kp.ring = uni(pc.ring);
+  kp.wb_cap = uni(pc.wb_cap);
+  kp.sb_cap = uni(pc.sb_cap);
+  kp.pen.x = uni(pc.x);
+  kp.pen.o1 = uni(pc.o1);
+  kp.pen.e1 = uni(pc.e1);
+  kp.pen.o2 = uni(pc.o2);
+  kp.pen.e2 = uni(pc.e2);
+  kp.pen.two_piece = P2 ? 1 : 0;
+  kp.pen.scope = max(kp.pen.x, max(kp.pen.o1 + kp.pen.e1, P2 ? kp.pen.o2 + kp.pen.e2 : 0)) + 1;
+  kp.lds_meta_bytes = uni(pc.lds_meta_bytes);
+  auto uni64 = [](unsigned long long v) { return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)v); };
+  SubCtx cx;
+  cx.plen = uni(pc.plen);
+  cx.tlen = uni(pc.tlen);
+  cx.kmin[0] = uni(pc.kmin[0]);
+  cx.kmin[1] = cx.kmin[0];
+  cx.wcols = uni(pc.wcols);
+  cx.seq_mode = uni(pc.seq_mode);
+  cx.p_w0 = uni(pc.p_w0);
+  cx.t_w0 = uni(pc.t_w0);
+  cx.p_bit = uni(pc.p_bit);
+  cx.t_bit = uni(pc.t_bit);
+  cx.P[0] = cx.P[1] = (gseq_t)(uintptr_t)uni64(pc.P[0]);
+  cx.T[0] = cx.T[1] = (gseq_t)(uintptr_t)uni64(pc.T[0]);
+  cx.Pw = nullptr;
+  cx.Tw = nullptr;
+  cx.pb_abs = cx.tb_abs = 0;
+  Lds<OffT> lds;
+  typedef typename MetaTraits<OffT>::Stored MetaStored;
+  lds.ring_meta = reinterpret_cast<MetaStored*>(dyn_smem);
+  lds.bi_A = reinterpret_cast<int*>(lds.ring_meta + 2 * NCOMP * kp.ring);
+  lds.bi_oob = lds.bi_A + 2 * kp.ring;
+  lds.firstk = lds.bi_oob + 2 * kp.ring;
+  lds.seq = reinterpret_cast<uint32_t*>(dyn_smem + kp.lds_meta_bytes);
+  lds.meta_log = (RowMeta*)(uintptr_t)uni64(pc.meta_log);
+  const rsrc_t rs = make_rsrc((void*)(uintptr_t)uni64(pc.ring_mem), (size_t)uni64(pc.ring_bytes));
+  const int end_comp = uni(pc.end_comp);
+  const int end_col = (cx.tlen - cx.plen) - cx.kmin[0];
+  int npass = 0, why = MP_MARGIN;
+  unsigned long long cells = 0;
+  unsigned ext_iters = 0;
+  for (;;) {
+    if (sc + Tn > kp.sb_cap) { why = MP_MARGIN; break; }  // the last scores before the capacity bound: step by step (they report CAPACITY themselves)
+    const int aslot = pass % 3;
+    MultiPlan mp;
+    plan_multi<P2, OffT, E1, E2, true>(kp, lds, cx, 0, sc, Tn, mp);
+    mp.end_comp = end_comp;
+    mp.end_col = end_col;
+    const int nc = compute_rows_multi<P2, OffT, E1, E2, true>(kp, sh, lds, cx, rs, 0, sc, mp, sh.acc[aslot][0], ext_iters);
+    __syncthreads();
+    if (uni(sh.error)) { why = MP_ERROR; break; }
+    if (uni(sh.acc[aslot][0].oob) != 0) { why = MP_DISCARD; break; }  // the pass assumed untrimmed rows
+    const int reach = uni(sh.acc[aslot][0].reach);
+    if (threadIdx.x == 0) acc_reset(sh.acc[(pass + 2) % 3][0]);
+    ++pass;
+    ++npass;
+    if (reach) {  // the end cell was reached at the first such step: that score is the penalty
+      const int t_end = __builtin_ctz((unsigned)reach);
+      for (int t = 0; t <= t_end; ++t)
+        if (mp.lo[t] <= mp.hi[t]) cells += (unsigned long long)(mp.hi[t] - mp.lo[t] + 1);
+      sc += t_end + 1;
+      why = MP_MET;
+      break;
+    }
+    cells += (unsigned long long)nc;
+    sc += Tn;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PhaseResult& pr = sh.pres;
+    pr.why = why;
+    pr.sc = sc;
+    pr.fmax = pr.rmax = 0;
+    pr.npass = npass;
+    pr.cells = cells;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { acc_reset(sh.acc[i][0]); acc_reset(sh.acc[i][1]); }
   }
   atomicAdd(&sh.ext_multi, (unsigned long long)ext_iters);
   __syncthreads();
@@ -1460,6 +1655,28 @@ __device__ __forceinline__ int base_align(const KParams& kp, Shared& sh, const L
     acc_reset(sh.acc[1][0]);
     acc_reset(sh.acc[2][0]);
   }
+  constexpr bool MULTI_BUILD = sizeof(OffT) == 2 && !DIRSPLIT;
+  const unsigned sh_addr = (unsigned)(uintptr_t)&sh, dyn_addr = (unsigned)(uintptr_t)lds.ring_meta;  // LDS addresses
+  if (MULTI_BUILD && tid == 0) {  // what base_phase reads back (uniform; the barrier below publishes it)
+    PassCtx& pc = sh.pctx;
+    pc.ring_mem = (unsigned long long)(uintptr_t)hist_mem;
+    pc.ring_bytes = (unsigned long long)kp.hist_slot_stride;
+    pc.meta_log = (unsigned long long)(uintptr_t)lds.meta_log;
+    pc.P[0] = pc.P[1] = (unsigned long long)(uintptr_t)cx.P[0];
+    pc.T[0] = pc.T[1] = (unsigned long long)(uintptr_t)cx.T[0];
+    pc.ring = kp.ring;
+    pc.wcap = kp.wcap;
+    pc.wb_cap = kp.wb_cap;
+    pc.sb_cap = kp.sb_cap;
+    pc.end_comp = ce;
+    pc.x = pn.x; pc.o1 = pn.o1; pc.e1 = pn.e1; pc.o2 = pn.o2; pc.e2 = pn.e2;
+    pc.lds_meta_bytes = kp.lds_meta_bytes;
+    pc.plen = plen; pc.tlen = tlen;
+    pc.kmin[0] = pc.kmin[1] = cx.kmin[0];
+    pc.wcols = cx.wcols;
+    pc.seq_mode = cx.seq_mode; pc.p_w0 = cx.p_w0; pc.t_w0 = cx.t_w0; pc.p_bit = cx.p_bit; pc.t_bit = cx.t_bit;
+    sh.ext_multi = 0;
+  }
   __syncthreads();
   const int k_end = tlen - plen;
   int score = 0;
@@ -1467,6 +1684,7 @@ __device__ __forceinline__ int base_align(const KParams& kp, Shared& sh, const L
   unsigned long long cells = 0;
   int pass = 0;
   bool dirty = false;  // some row of this sub-problem was trimmed: later steps mask element by element
+  bool multi_open = MULTI_BUILD && kp.multi_T > 0;  // multi-step passes (base_phase) until one is discarded or the capacity bound is near
   const unsigned long long tb0 = PROF_NOW();
   for (;;) {
     // termination (wavefront_termination_end2end): end component reaches (plen, tlen)
@@ -1474,6 +1692,21 @@ __device__ __forceinline__ int base_align(const KParams& kp, Shared& sh, const L
     if (k_end >= me.lo && k_end <= me.hi) {
       const int32_t v = uni(off_load1<OffT>(hist + ((size_t)score * NCOMP + ce) * (size_t)kp.wb_cap + (k_end - kmin)));
       if (v >= tlen) break;
+    }
+    if (MULTI_BUILD && multi_open && !dirty) {
+      if constexpr (MULTI_BUILD) {
+        if (P2 || pn.e1 == 1) base_phase<P2, OffT, P2 ? 2 : 1, 1>(sh_addr, dyn_addr, score, kp.multi_T, pass);
+        else base_phase<P2, OffT, 2, 1>(sh_addr, dyn_addr, score, kp.multi_T, pass);
+      }
+      const int why = uni(sh.pres.why);
+      if (why == MP_ERROR) return uni(sh.error);
+      score = uni(sh.pres.sc);
+      pass += uni(sh.pres.npass);
+      cells += ((unsigned long long)(unsigned)uni((int)(sh.pres.cells >> 32)) << 32) | (unsigned)uni((int)sh.pres.cells);
+      multi_open = false;  // (discarded pass or capacity margin: the rest goes step by step)
+      __syncthreads();     // (sh.pres may be rewritten only after everyone has read it)
+      if (why == MP_MET) break;  // `score` is the first score at which the end cell was reached
+      continue;
     }
     ++score;
     if (score > kp.sb_cap) return ST_CAPACITY;
@@ -1501,6 +1734,7 @@ __device__ __forceinline__ int base_align(const KParams& kp, Shared& sh, const L
     lstats[STAT_BASE] += 1;
   }
   atomicAdd(&lstats[STAT_EXTEND], (unsigned long long)ext_iters);
+  if (MULTI_BUILD && tid == 0) lstats[STAT_EXTEND] += sh.ext_multi;
   // ---- backtrace by wave 0 (candidates fetched by lanes 0..8, packed (offset<<4)|type, max wins)
   if (tid < 64) {
     int matrix = ce, sc = score, k = k_end, offset = tlen;
@@ -1950,6 +2184,7 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
           if (P2 || pn.e1 == 1) multi_phase<P2, OffT, P2 ? 2 : 1, 1>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
           else multi_phase<P2, OffT, 2, 1>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
         }
+        PROF_ADD(STAT_T_BI_COMPUTE, tp0);
         const int why = uni(sh.pres.why);
         if (why == MP_ERROR) { rc = uni(sh.error); break; }
         if (why == MP_MET) { rc = BP_RESTART; break; }
@@ -2089,7 +2324,7 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
     if (tid == 0) {
       sh.cur_pair = (long long)atomicAdd(kp.work_counter, 1ULL);
       sh.error = 0;
-      sh.win_single = sh.win_multi = sh.win_base = 0;
+      sh.win_single = sh.win_multi = sh.win_base = sh.win_base_multi = 0;
     }
     __syncthreads();
     const long long pair = ((long long)uni((int)(sh.cur_pair >> 32)) << 32) | (unsigned)uni((int)sh.cur_pair);
@@ -2204,8 +2439,8 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
       r.t_end = em.cnt[0] + em.cnt[1] + em.cnt[2];
       kp.results[pair] = r;
       PROF_ADD(STAT_T_TOTAL, tt0);
-      lstats[STAT_WIN_SINGLE] += sh.win_single; lstats[STAT_WIN_MULTI] += sh.win_multi; lstats[STAT_WIN_BASE] += sh.win_base;
-      sh.win_single = sh.win_multi = sh.win_base = 0;
+      lstats[STAT_WIN_SINGLE] += sh.win_single; lstats[STAT_WIN_MULTI] += sh.win_multi; lstats[STAT_WIN_BASE] += sh.win_base; lstats[STAT_WIN_BASE_MULTI] += sh.win_base_multi;
+      sh.win_single = sh.win_multi = sh.win_base = sh.win_base_multi = 0;
       if (status == ST_OK) {
         lstats[STAT_ALIGNED_BP] += (unsigned long long)plenT;
         lstats[STAT_PAIRS] += 1;

@@ -152,7 +152,7 @@ namespace {
 
 int upload_seqset(awv_engine* e, SeqSet& s, int32_t n, const uint8_t* bytes, const uint64_t* offsets) {
   if (n < 0 || (n > 0 && (!bytes || !offsets))) return fail(AWV_ERR_ARG, "set_sequences: null input");
-  s.n = n;
+  s.n = 0;  // the set counts as loaded (awv_align_pairs passes its AWV_ERR_STATE check) only once every copy below has landed
   s.off.assign((size_t)n + 1, 0);
   s.len.assign((size_t)n, 0);
   uint64_t run = 0;
@@ -223,6 +223,7 @@ int upload_seqset(awv_engine* e, SeqSet& s, int32_t n, const uint8_t* bytes, con
   HIP_TRY(hipMemcpyAsync(s.d_off.p, s.off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
   if (n > 0) HIP_TRY(hipMemcpyAsync(s.d_len.p, s.len.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  s.n = n;
   return AWV_OK;
 }
 
@@ -317,8 +318,14 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   while (ring < dp.scope + 2 + (multi_T > 0 ? multi_T - 1 : 0)) ring *= 2;
   const int64_t max_batch = e->cfg.max_batch_pairs > 0 ? e->cfg.max_batch_pairs : (int64_t)1 << 20;
   uint64_t max_arena = e->cfg.max_arena_bytes > 0 ? (uint64_t)e->cfg.max_arena_bytes : (uint64_t)8 << 30;
-  if (const char* env = getenv("AWV_MAX_ARENA_MB")) max_arena = std::max<uint64_t>(1, (uint64_t)atoll(env)) << 20;  // experiment knob
-  const bool inline_sink = getenv("AWV_INLINE_SINK") != nullptr;  // experiment knob: every sink on the calling thread
+  // Experiment knobs read from the environment exist only in a -DAWV_DEBUG_KNOBS build; the product library's
+  // behaviour depends on its arguments alone.
+#ifdef AWV_DEBUG_KNOBS
+  if (const char* env = getenv("AWV_MAX_ARENA_MB")) max_arena = std::max<uint64_t>(1, (uint64_t)atoll(env)) << 20;
+  const bool inline_sink = getenv("AWV_INLINE_SINK") != nullptr;  // every sink on the calling thread
+#else
+  const bool inline_sink = false;
+#endif
   // base-case capacities: score_remaining <= 250 or both lengths <= 100
   // A sub-problem that ends in an indel component pays that gap's open on top of the
   // score_remaining its parent hands down (the reverse aligner starts with the open pre-paid).
@@ -333,7 +340,11 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
            ~(size_t)15;
   };
 
+#ifdef AWV_DEBUG_KNOBS
   const bool timing = getenv("AWV_TIMING") != nullptr;  // diagnostic: host-side stage times on stderr
+#else
+  const bool timing = false;
+#endif
   const auto tl0 = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
     if (timing) fprintf(stderr, "[awv] %-22s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count());
@@ -423,14 +434,14 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     // One group of the batch = one kernel flavour: `wide` pairs get a 256-thread workgroup each (four
     // waves deal a row's windows among themselves), the others one wave each.
     auto run_group = [&](std::vector<int32_t> hq, std::vector<int32_t> ht, std::vector<int32_t> hrc, std::vector<uint64_t> hoff,
-                         std::vector<int64_t> amap, int waves, int g_maxsum, int g_maxlen, bool reserve_only) -> int {
+                         std::vector<int64_t> amap, int waves, bool narrow, int g_maxsum, int g_maxlen, bool reserve_only) -> int {
     if (hq.empty()) return AWV_OK;
     const int wg = waves == 1 ? AWV_THRU_WG : 64 * waves;
     const int nslots_g = e->cfg.workgroups > 0 ? std::max(1, e->cfg.workgroups / (wg / 64)) : (WAVES_PER_SIMD * 256 / wg) * e->num_cus;
     const int wcap_full = ((g_maxsum + 9 + 256 + 2 * COL_PAD) + 255) & ~255;
     const int nslots_want = (int)std::min<int64_t>(nslots_g, (int64_t)hq.size());
-    // 16-bit wavefront rows whenever every offset fits (halves the HBM/L2 traffic of the rings)
-    const bool narrow = g_maxlen < 32760 && !(e->cfg.flags & AWV_F_FORCE_INT32);
+    // 16-bit wavefront rows whenever every offset fits (halves the HBM/L2 traffic of the rings): the caller
+    // groups pairs by row width, so one long sequence no longer drags a whole batch to 32-bit rows
     const size_t esz = narrow ? 2 : 4;
     // dynamic LDS = ring metadata (16-bit entries with 16-bit rows) + staging of the 2-bit packed
     // sequences: what the largest pair needs, within 160 KB / (16 waves per CU) per workgroup;
@@ -467,8 +478,8 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       wc = std::max<long long>(wc & ~255LL, 8192);
       wcap = (int)std::min<long long>(wcap, wc);
     }
-    if (const char* env = getenv("AWV_WCAP_MAX")) wcap = std::min(wcap, std::max(2048, atoi(env)));  // experiment knob
-    if (const char* env = getenv("AWV_ROW_PAD")) wcap += atoi(env);  // experiment knob: extra columns per row (row / slot stride phase)
+    // (diagnostic / test hook: a narrower first attempt, so that the CAPACITY re-run path can be exercised on short sequences)
+    if (e->cfg.first_row_cols > 0) wcap = std::min(wcap, std::max(2048, (e->cfg.first_row_cols + 255) & ~255));
     // ---- attempts: the whole batch at row capacity `wcap`, then only the pairs that outgrew it
     std::vector<awv_result> tres;
     float ms = 0;
@@ -486,7 +497,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
         size_t free_b = 0, total_b = 0;
         e->ring_mem.release();
         (void)hipMemGetInfo(&free_b, &total_b);
-        int ncand = (getenv("AWV_NO_ARENA_PROBE") || (e->cfg.flags & AWV_F_NO_ARENA_PROBE)) ? 1 : 4;
+        int ncand = (e->cfg.flags & AWV_F_NO_ARENA_PROBE) ? 1 : 4;
         while (ncand > 1 && (size_t)ncand * want > free_b / 10 * 8) --ncand;  // all candidates are alive at once
         const bool probe_ok = ncand > 1 && want >= ((size_t)1 << 30) && esz == 2 && ring_stride >= (size_t)2 * 5 * 32 * 4096 &&
                               (size_t)wc * esz >= 4096;
@@ -498,15 +509,21 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
           if (hipMalloc((void**)&cand[c], want) != hipSuccess) { cand[c] = nullptr; (void)hipGetLastError(); break; }
           if (ncand == 1) { best = 0; break; }
           float tbest = 1e30f;
-          for (int rep = 0; rep < 2; ++rep) {
-            HIP_TRY(hipEventRecord(e->ev0, e->stream));
+          hipError_t perr = hipSuccess;
+          for (int rep = 0; rep < 2 && perr == hipSuccess; ++rep) {
+            float pms = 0;
+            if ((perr = hipEventRecord(e->ev0, e->stream)) != hipSuccess) break;
             hipLaunchKernelGGL(arena_probe_kernel, dim3(nslots), dim3(64), 0, e->stream, cand[c], ring_stride, (int)((size_t)wc * esz), 24,
                                std::min(1400, wc - 2048), e->d_counters.p);
-            HIP_TRY(hipEventRecord(e->ev1, e->stream));
-            HIP_TRY(hipEventSynchronize(e->ev1));
-            float pms = 0;
-            HIP_TRY(hipEventElapsedTime(&pms, e->ev0, e->ev1));
+            if ((perr = hipEventRecord(e->ev1, e->stream)) != hipSuccess) break;
+            if ((perr = hipEventSynchronize(e->ev1)) != hipSuccess) break;
+            if ((perr = hipEventElapsedTime(&pms, e->ev0, e->ev1)) != hipSuccess) break;
             tbest = std::min(tbest, pms);
+          }
+          if (perr != hipSuccess) {  // nothing may stay allocated behind an error return
+            for (int k = 0; k < 4; ++k)
+              if (cand[k]) (void)hipFree(cand[k]);
+            return fail(AWV_ERR_HIP, std::string("ring arena probe: ") + hipGetErrorString(perr));
           }
           cms[c] = tbest;
           if (best < 0 || tbest < cms[best]) best = c;
@@ -634,25 +651,31 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     return AWV_OK;
     };
     {
-      // which pairs go wide: all of a small batch (latency), all pairs of long sequences (their rows are
-      // tens of windows wide; measured +17 % on 100 kbp pairs), and pairs a length difference makes expensive
+      // One group = one kernel flavour x one row width.  Flavour: all of a small batch goes four waves per pair
+      // (latency), and so do pairs of long sequences (rows tens of windows wide; measured +17 % on 100 kbp
+      // pairs) and pairs a length difference makes expensive -- pair by pair, so that the short pairs of a
+      // mixed set (config 5) keep the throughput flavour.  Row width: 16-bit rows when both lengths fit.
       const bool never_wide = (e->cfg.flags & AWV_F_ONE_WAVE) != 0;
       // (a batch of uneven pairs that fits the machine about once is bound by its longest pairs, not by throughput)
-      const bool all_wide = !never_wide && ((e->cfg.flags & AWV_F_FOUR_WAVES) || n <= (int64_t)(WAVES_PER_SIMD * e->num_cus) || maxlen >= 32760 ||
+      const bool all_wide = !never_wide && ((e->cfg.flags & AWV_F_FOUR_WAVES) || n <= (int64_t)(WAVES_PER_SIMD * e->num_cus) ||
                                             (skewed && n <= (int64_t)(4 * WAVES_PER_SIMD * e->num_cus)));
-      std::vector<int32_t> q[3], t[3], rc[3];
-      std::vector<uint64_t> off[3];
-      std::vector<int64_t> map[3];
-      int gsum[3] = {0, 0, 0}, glen[3] = {0, 0, 0};
+      constexpr int NG = 6;  // group = flavour (0 one wave, 1 four, 2 sixteen) * 2 + (32-bit rows ? 1 : 0)
+      std::vector<int32_t> q[NG], t[NG], rc[NG];
+      std::vector<uint64_t> off[NG];
+      std::vector<int64_t> map[NG];
+      int gsum[NG] = {0}, glen[NG] = {0};
       // sixteen waves per pair only pay while such pairs are too few to fill the machine four waves at a time
       int64_t n_huge = 0;
       for (int64_t i = 0; i < n; ++i) n_huge += std::abs(s.len[hq[(size_t)i]] - s.len[ht[(size_t)i]]) >= 16384;
       const bool use_sixteen = !never_wide && !(e->cfg.flags & AWV_F_FOUR_WAVES) && n_huge > 0 && n_huge <= (int64_t)e->num_cus;
+      const bool force32 = (e->cfg.flags & AWV_F_FORCE_INT32) != 0;
       for (int64_t i = 0; i < n; ++i) {
         const int ql = s.len[hq[(size_t)i]], tl = s.len[ht[(size_t)i]];
         const int dl = std::abs(ql - tl);
-        int g = (all_wide || (!never_wide && dl >= 4096)) ? 1 : 0;
-        if (use_sixteen && dl >= 16384) g = 2;  // a forced gap that long: rows hundreds of windows wide
+        const bool wide_rows = force32 || std::max(ql, tl) >= 32760;
+        int f = (all_wide || (!never_wide && (dl >= 4096 || std::max(ql, tl) >= 32760))) ? 1 : 0;
+        if (use_sixteen && dl >= 16384) f = 2;  // a forced gap that long: rows hundreds of windows wide
+        const int g = f * 2 + (wide_rows ? 1 : 0);
         q[g].push_back(hq[(size_t)i]); t[g].push_back(ht[(size_t)i]); rc[g].push_back(hrc[(size_t)i]); off[g].push_back(hoff[(size_t)i]);
         map[g].push_back(amap.empty() ? i : amap[(size_t)i]);
         gsum[g] = std::max(gsum[g], ql + tl);
@@ -662,23 +685,24 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       // the arenas are sized for the most demanding group first: growing them between two groups would
       // mean a free followed by a large allocation, which the driver can take seconds over
       {  // (reserve in descending order of estimated ring demand; DevBuf::reserve only ever grows)
-        std::pair<size_t, int> demand[3];
-        for (int g = 0; g < 3; ++g) {
+        std::pair<size_t, int> demand[NG];
+        for (int g = 0; g < NG; ++g) {
           demand[g] = {0, g};
           if (q[g].empty()) continue;
-          const int wgx = waves_of[g] == 1 ? AWV_THRU_WG : 64 * waves_of[g];
+          const int wv = waves_of[g / 2];
+          const int wgx = wv == 1 ? AWV_THRU_WG : 64 * wv;
           const int64_t slots = std::min<int64_t>((WAVES_PER_SIMD * 256 / wgx) * e->num_cus, (int64_t)q[g].size());
-          demand[g].first = (size_t)slots * (size_t)gsum[g] * (glen[g] < 32760 ? 2 : 4);
+          demand[g].first = (size_t)slots * (size_t)gsum[g] * ((g & 1) ? 4 : 2);
         }
-        std::sort(demand, demand + 3, [](const std::pair<size_t, int>& a, const std::pair<size_t, int>& b) { return a.first > b.first; });
-        for (int k = 0; k < 3; ++k) {
+        std::sort(demand, demand + NG, [](const std::pair<size_t, int>& a, const std::pair<size_t, int>& b) { return a.first > b.first; });
+        for (int k = 0; k < NG; ++k) {
           const int g = demand[k].second;
           if (q[g].empty()) continue;
-          if (int rcg = run_group(q[g], t[g], rc[g], off[g], map[g], waves_of[g], gsum[g], glen[g], true)) return rcg;
+          if (int rcg = run_group(q[g], t[g], rc[g], off[g], map[g], waves_of[g / 2], !(g & 1), gsum[g], glen[g], true)) return rcg;
         }
       }
-      for (int g = 2; g >= 0; --g)
-        if (int rcg = run_group(std::move(q[g]), std::move(t[g]), std::move(rc[g]), std::move(off[g]), std::move(map[g]), waves_of[g], gsum[g], glen[g], false)) return rcg;
+      for (int g = NG - 1; g >= 0; --g)
+        if (int rcg = run_group(std::move(q[g]), std::move(t[g]), std::move(rc[g]), std::move(off[g]), std::move(map[g]), waves_of[g / 2], !(g & 1), gsum[g], glen[g], false)) return rcg;
     }
     const bool want_cigar = sink && !(e->cfg.flags & AWV_F_KEEP_ON_DEVICE);
     lap("results on host");
@@ -737,6 +761,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   e->stats.windows[0] = stat_tot[STAT_WIN_SINGLE];
   e->stats.windows[1] = stat_tot[STAT_WIN_MULTI];
   e->stats.windows[2] = stat_tot[STAT_WIN_BASE];
+  e->stats.windows[3] = stat_tot[STAT_WIN_BASE_MULTI];
   return AWV_OK;
 }
 

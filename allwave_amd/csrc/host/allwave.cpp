@@ -295,7 +295,11 @@ AllPairIterator& AllPairIterator::with_shard(size_t rank, size_t world) {
 
 void AllPairIterator::run(const std::function<void(int64_t, int64_t, const awv_result*, const uint8_t*,
                                                    const std::vector<uint8_t>&)>& batch_cb) {
+#ifdef AWV_DEBUG_KNOBS
   const bool timing = getenv("AWH_TIMING") != nullptr;  // diagnostic: stage times on stderr
+#else
+  const bool timing = false;
+#endif
   const auto tr0 = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
     if (timing) fprintf(stderr, "[awh] %-18s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count());
@@ -383,7 +387,9 @@ void AllPairIterator::for_each_paf_batch(const std::function<void(const std::str
       });
     }
     for (auto& x : th) x.join();
+#ifdef AWV_DEBUG_KNOBS
     if (getenv("AWH_TIMING")) fprintf(stderr, "[awh] formatted %lld pairs on %d threads\n", (long long)cnt, T);
+#endif
     for (const auto& p : parts) sink(p);
   });
 }

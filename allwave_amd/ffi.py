@@ -29,7 +29,7 @@ EXPORTS = ("awv_abi_version", "awv_last_error", "awv_engine_create", "awv_engine
 
 class EngineConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("workgroups", C.c_int32), ("max_batch_pairs", C.c_int64),
-                ("max_arena_bytes", C.c_int64), ("flags", C.c_int32), ("reserved", C.c_int32),
+                ("max_arena_bytes", C.c_int64), ("flags", C.c_int32), ("first_row_cols", C.c_int32),
                 ("max_scratch_bytes", C.c_int64)]
 
 
@@ -55,7 +55,7 @@ class Stats(C.Structure):
                 ("launches", C.c_uint64), ("cell_steps", C.c_uint64), ("extend_steps", C.c_uint64),
                 ("n_breakpoints", C.c_uint64), ("n_base", C.c_uint64), ("overlap_scans", C.c_uint64),
                 ("aligned_bp", C.c_uint64), ("pairs_completed", C.c_uint64), ("scratch_bytes", C.c_uint64),
-                ("prof", C.c_uint64 * 14), ("restarts", C.c_uint64), ("multi_cell_steps", C.c_uint64), ("windows", C.c_uint64 * 3)]
+                ("prof", C.c_uint64 * 14), ("restarts", C.c_uint64), ("multi_cell_steps", C.c_uint64), ("windows", C.c_uint64 * 4)]
 
 
 PAIR_DTYPE = np.dtype([("q_idx", "<i4"), ("t_idx", "<i4"), ("q_revcomp", "<i4")])
@@ -100,10 +100,10 @@ class EngineError(RuntimeError):
 class Engine:
     """One engine per GPU (owns device copies of the sequences, scratch arenas, one stream)."""
 
-    def __init__(self, device=0, workgroups=0, max_batch_pairs=0, max_arena_bytes=0, flags=0, max_scratch_bytes=0):
+    def __init__(self, device=0, workgroups=0, max_batch_pairs=0, max_arena_bytes=0, flags=0, max_scratch_bytes=0, first_row_cols=0):
         L = load()
         self._h = C.c_void_p()
-        cfg = EngineConfig(device, workgroups, max_batch_pairs, max_arena_bytes, flags, 0, max_scratch_bytes)
+        cfg = EngineConfig(device, workgroups, max_batch_pairs, max_arena_bytes, flags, first_row_cols, max_scratch_bytes)
         rc = L.awv_engine_create(C.byref(cfg), C.byref(self._h))
         if rc != AWV_OK:
             self._h = C.c_void_p()

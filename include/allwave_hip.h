@@ -70,7 +70,8 @@ typedef struct {
   int64_t max_batch_pairs; /* pairs per launch (0 = default) */
   int64_t max_arena_bytes; /* CIGAR arena budget per launch (0 = default 8 GiB) */
   int32_t flags;           /* AWV_F_* */
-  int32_t reserved;
+  int32_t first_row_cols;  /* 0 = default; > 0 caps the row width (columns, >= 2048) of a batch's first attempt: pairs whose
+                              wavefronts outgrow it come back CAPACITY and are re-run wider (diagnostic / test hook) */
   int64_t max_scratch_bytes; /* cap on the per-workgroup wavefront arenas (0 = default 160 GiB) */
 } awv_engine_config;
 
@@ -143,7 +144,7 @@ typedef struct {
   uint64_t prof[14];
   uint64_t restarts;          /* breakpoint searches run again step by step (multi-step passes met too early) */
   uint64_t multi_cell_steps;  /* cells computed by multi-step passes (I/D rows kept in registers) */
-  uint64_t windows[3];        /* window iterations: [0] step-by-step (one step each), [1] multi-step passes (T steps each), [2] base case */
+  uint64_t windows[4];        /* window iterations: [0] step-by-step (one step each), [1] multi-step passes (T steps each), [2] base case step-by-step, [3] base case multi-step passes */
 } awv_stats;
 
 int awv_abi_version(void);

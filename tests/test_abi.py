@@ -30,7 +30,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(ffi.Penalties) == 28
     assert ffi.PAIR_DTYPE.itemsize == 12
     assert ffi.RESULT_DTYPE.itemsize == 48
-    assert C.sizeof(ffi.Stats) == 8 * 31
+    assert C.sizeof(ffi.Stats) == 8 * 32
 
 
 def test_flag_and_status_constants_match_header():

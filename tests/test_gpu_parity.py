@@ -243,7 +243,7 @@ def test_long_sequences_use_32bit_rows(engine, oracle):
     assert st.n_breakpoints > 10 and st.pairs_completed == 4
 
 
-def test_narrow_first_attempt_is_rerun_with_wider_rows(oracle, monkeypatch):
+def test_narrow_first_attempt_is_rerun_with_wider_rows(oracle):
     """Long sequences start with rows narrower than plen + tlen; pairs whose wavefronts outgrow them
     come back CAPACITY from the first launch and are re-run wider.  Forced here on 6 kbp pairs by
     capping the first attempt at 2048 columns: several launches, identical results."""
@@ -252,8 +252,7 @@ def test_narrow_first_attempt_is_rerun_with_wider_rows(oracle, monkeypatch):
     a = rand_seq(rng, 6000)
     seqs = [a, mutate(a, 0.08, rng), mutate(a, 0.01, rng), rand_seq(rng, 1500)]
     pairs = [(i, j) for i in range(4) for j in range(4) if i != j]
-    monkeypatch.setenv("AWV_WCAP_MAX", "2048")
-    e = ffi.Engine()
+    e = ffi.Engine(first_row_cols=2048)
     try:
         check_against_oracle(e, oracle, seqs, pairs, DEFAULT_2P)
         st = e.stats()

@@ -36,6 +36,109 @@ def test_siphash_core_matches_reference_vector(host):
     assert host.hash_str("a:b") != host.hash_str("b:a")
 
 
+def _siphash_py(key, msg, c, d):
+    """SipHash-c-d written out from the paper (Aumasson & Bernstein 2012, section 2) -- an implementation
+    independent of csrc/host/planner.cpp, pinned below by published vectors."""
+    import struct
+    M = (1 << 64) - 1
+    rotl = lambda x, b: ((x << b) | (x >> (64 - b))) & M
+    k0, k1 = struct.unpack("<QQ", key)
+    v = [k0 ^ 0x736f6d6570736575, k1 ^ 0x646f72616e646f6d, k0 ^ 0x6c7967656e657261, k1 ^ 0x7465646279746573]
+
+    def rnd():
+        v[0] = (v[0] + v[1]) & M; v[1] = rotl(v[1], 13); v[1] ^= v[0]; v[0] = rotl(v[0], 32)
+        v[2] = (v[2] + v[3]) & M; v[3] = rotl(v[3], 16); v[3] ^= v[2]
+        v[0] = (v[0] + v[3]) & M; v[3] = rotl(v[3], 21); v[3] ^= v[0]
+        v[2] = (v[2] + v[1]) & M; v[1] = rotl(v[1], 17); v[1] ^= v[2]; v[2] = rotl(v[2], 32)
+
+    n = len(msg)
+    b = (n & 0xFF) << 56
+    for i in range(0, n - n % 8, 8):
+        m = struct.unpack_from("<Q", msg, i)[0]
+        v[3] ^= m
+        for _ in range(c):
+            rnd()
+        v[0] ^= m
+    for i, x in enumerate(msg[n - n % 8:]):
+        b |= x << (8 * i)
+    v[3] ^= b
+    for _ in range(c):
+        rnd()
+    v[0] ^= b
+    v[2] ^= 0xFF
+    for _ in range(d):
+        rnd()
+    return v[0] ^ v[1] ^ v[2] ^ v[3]
+
+
+def test_siphash_known_answers(host):
+    """Known-answer vectors in the reference implementation's format (key 00..0f, message 00..n-1, output
+    as little-endian bytes): the first five of SipHash-2-4's published table (vectors.h `vectors_sip64`),
+    the paper's Appendix A value, and the first vector of the Rust standard library's own SipHash-1-3 test
+    (library/core/tests/hash/sip.rs `test_siphash_1_3`).  Then planner::siphash against the independent
+    implementation above on all 64 message lengths of that format for both variants, and the two
+    DefaultHasher framings the reference relies on (iterator.rs:261-281 `str`, alignment.rs:142-149 /
+    mash.rs:109-113 `[u8]`) on top of the zero-key 1-3 variant."""
+    key = bytes(range(16))
+    k0, k1 = int.from_bytes(key[:8], "little"), int.from_bytes(key[8:], "little")
+    published_24 = ["310e0edd47db6f72", "fd67dc93c539f874", "5a4fa9d909806c0d", "2d7efbd796666785", "b7877127e09427cf"]
+    for n, hexv in enumerate(published_24):
+        assert host.siphash(bytes(range(n)), k0, k1, 2, 4).to_bytes(8, "little").hex() == hexv
+        assert _siphash_py(key, bytes(range(n)), 2, 4).to_bytes(8, "little").hex() == hexv
+    assert host.siphash(bytes(range(15)), k0, k1, 2, 4) == 0xA129CA6149BE45E5
+    assert host.siphash(b"", k0, k1, 1, 3).to_bytes(8, "little").hex() == "dcc40f055801acab"  # Rust's test_siphash_1_3, vector 0
+    assert _siphash_py(key, b"", 1, 3).to_bytes(8, "little").hex() == "dcc40f055801acab"
+    for n in range(64):
+        msg = bytes(range(n))
+        assert host.siphash(msg, k0, k1, 1, 3) == _siphash_py(key, msg, 1, 3), n
+        assert host.siphash(msg, k0, k1, 2, 4) == _siphash_py(key, msg, 2, 4), n
+        assert host.siphash(msg, 0, 0, 1, 3) == _siphash_py(bytes(16), msg, 1, 3), n  # DefaultHasher::new(): zero keys
+    zero = bytes(16)
+    for kmer in (b"ACGTACGTACGTACG", b"A" * 15, b"acgtnACGTN", b""):
+        assert host.hash_bytes(kmer) == _siphash_py(zero, len(kmer).to_bytes(8, "little") + kmer, 1, 3)
+    for text in ("s00001:s00002", "seq1:seq2", ""):
+        assert host.hash_str(text) == _siphash_py(zero, text.encode() + b"\xff", 1, 3)
+
+
+def test_reference_unit_tests_restated(host):
+    """The assertions of the reference's own unit tests, on the reference's own inputs:
+    src/mash.rs:186-260 (identical sequences: Jaccard 1 / distance ~0; distance matrix of three 16-mers)
+    and src/knn_graph.rs:195-387 (kNN / stranger / tree pair counts, empty and single-sequence sets)."""
+    s_a, s_g = b"ATCGATCGATCGATCG", b"GGGGGGGGGGGGGGGG"
+    # mash.rs test_distance_matrix (compute_distance_matrix: k = 15, sketch 1000)
+    m = host.mash_matrix(["seq1", "seq2", "seq3"], [s_a, s_a, s_g], k=15)
+    assert m.shape == (3, 3)
+    assert m[0, 0] < 1e-6 and m[1, 1] < 1e-6 and m[2, 2] < 1e-6
+    assert m[0, 1] < 1e-6 and m[1, 0] < 1e-6
+    assert m[0, 2] > 0.0 and m[2, 0] > 0.0
+    # mash.rs test_jaccard_identical / test_mash_distance_identical: `ATCGATCGATCG`, k = 4
+    m4 = host.mash_matrix(["a", "b"], [b"ATCGATCGATCG", b"ATCGATCGATCG"], k=4)
+    assert m4[0, 1] < 1e-10
+    # mash.rs test_reverse_complement: reverse_complement_kmer(b"ATCG") == b"CGAT"
+    assert host.reverse_complement(b"ATCG") == b"CGAT"
+    # knn_graph.rs test_knn_graph_basic: extract_knn_pairs(k = 1, no random) on seq1 == seq2 != seq3
+    ids3, seqs3 = ["seq1", "seq2", "seq3"], [s_a, s_a, s_g]
+    p = host.plan_pairs(ids3, seqs3, "tree:1:0:0")
+    assert 2 <= len(p) <= 3
+    # test_tree_sampling_with_strangers: 1 nearest + 1 farthest
+    p = host.plan_pairs(ids3, seqs3, "tree:1:1:0")
+    assert 4 <= len(p) <= 6
+    # test_only_nearest_neighbors / test_only_strangers
+    assert len(host.plan_pairs(["seq1", "seq2"], [s_a, s_a], "tree:1:0:0")) == 2
+    assert len(host.plan_pairs(["seq1", "seq2"], [s_a, s_g], "tree:0:1:0")) == 2
+    # test_empty_sequences / test_single_sequence
+    assert host.plan_pairs([], [], "tree:1:0:0") == []
+    assert host.plan_pairs(["seq1"], [b"ATCG"], "tree:1:0:0") == []
+    # test_build_knn_graph / test_build_knn_graph_farthest / test_knn_with_k_equals_2
+    d3 = [[0.0, 0.1, 0.9], [0.1, 0.0, 0.8], [0.9, 0.8, 0.0]]
+    near = host.knn_graph(d3, 1)
+    assert len(near) == 3 and (0, 1) in near and (1, 0) in near and ((2, 0) in near or (2, 1) in near)
+    far = host.knn_graph(d3, 1, farthest=True)
+    assert len(far) == 3 and (0, 2) in far and (1, 2) in far and ((2, 0) in far or (2, 1) in far)
+    d4 = [[0.0, 0.1, 0.5, 0.9], [0.1, 0.0, 0.6, 0.8], [0.5, 0.6, 0.0, 0.2], [0.9, 0.8, 0.2, 0.0]]
+    assert len(host.knn_graph(d4, 2)) == 8
+
+
 def test_connectivity_probability(host):
     """iterator.rs:300-334"""
     assert host.connectivity_probability(1, 0.99) == 1.0
