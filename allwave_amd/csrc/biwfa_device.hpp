@@ -107,6 +107,7 @@ struct KParams {
   long long npairs;
   DevPenalties pen;
   int ring;        // power of two >= scope + 2 (+ multi_T - 1 with multi-step passes)
+  int chain_max;   // sweeps a multi-step pass may chain (1: none; > 1 needs x == TMAX and o1 + e1 == 2 TMAX, ring >= scope + 2 + TMAX * chain_max - 1)
   int multi_T;     // steps per multi-step pass (0: off): <= min(TMAX, x, o1+e1, o2+e2, ring - scope - 1), e1/e2 among the instantiated depths
   int wcap;        // columns per ring row
   void* ring_mem;
@@ -130,7 +131,7 @@ struct KParams {
 struct RowMeta { int lo, hi; };
 constexpr int K_BIG = 1 << 28;  // an empty row is {K_BIG, -K_BIG}: min/max hulls ignore it for free
 #define ROW_EMPTY RowMeta{K_BIG, -K_BIG}
-struct Acc { int hull_lo[NCOMP]; int hull_hi[NCOMP]; int maxak; int oob; int maxak_t[8]; int reach; };  // maxak_t: per step of a multi-step pass
+struct Acc { int hull_lo[NCOMP]; int hull_hi[NCOMP]; int maxak; int oob; int reach; };  // maxak_t: per step of a multi-step pass
 struct Task { int pb, pe, tb, te, cb, ce, score_remaining, known; };  // known: the sub-problem's optimal score (INT_MAX at the top)
 struct Breakpoint { int score, sf, sr, kf, kr, off_f, off_r, comp; };
 
@@ -171,6 +172,7 @@ struct PassCtx {
   int ring, wcap;
   int x, o1, e1, o2, e2;
   int lds_meta_bytes;
+  int chain_max;
   int plen, tlen, kmin[2], wcols;
   int seq_mode, p_w0, t_w0, p_bit, t_bit;
   // base case (base_phase): history arena instead of the ring, the metadata log, capacities, the end cell
@@ -180,6 +182,7 @@ struct PassCtx {
 struct PhaseResult { int why, sc, fmax, rmax, npass; unsigned long long cells; };
 struct Shared {
   Acc acc[3][2];
+  int chain_maxak[2][16];  // multi_phase: per direction and step of the running pass, the row's max antidiagonal
   PassCtx pctx;
   PhaseResult pres;
   unsigned long long ext_multi;  // extend probes counted by multi-step passes
@@ -455,8 +458,6 @@ __device__ __forceinline__ void acc_reset(Acc& a) {
   for (int c = 0; c < NCOMP; ++c) { a.hull_lo[c] = INT_MAX; a.hull_hi[c] = INT_MIN; }
   a.maxak = 0;
   a.oob = 0;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) a.maxak_t[t] = 0;
   a.reach = 0;
 }
 
@@ -915,26 +916,32 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
 #ifndef AWV_TMAX
 #define AWV_TMAX 5
 #endif
-constexpr int TMAX = AWV_TMAX;
-constexpr int MHALO = (TMAX + 3) / 4;       // unproductive lanes on either side of a window
-constexpr int MPROD = 64 - 2 * MHALO;       // productive lanes
-constexpr int MSTRIDE = MPROD * 4;          // new columns per window
-#ifndef AWV_MEXT_GROUP
-#define AWV_MEXT_GROUP 1
+constexpr int TMAX = AWV_TMAX;  // steps per sweep (one burst of row loads)
+#ifndef AWV_CHAIN_MAX
+#define AWV_CHAIN_MAX 3
 #endif
-constexpr int MEXT_GROUP = AWV_MEXT_GROUP;  // steps whose extension probes are issued together
-static_assert(TMAX >= 2 && TMAX <= 8, "pass length");
+// Chained sweeps: with T = TMAX = x and o1 + e1 = 2 x (the default scores: 5 and 10) the M rows a sweep needs
+// from 5 and 10 scores back are exactly the previous one / two sweeps' own results, so up to CHAIN_MAX sweeps
+// of one window run back to back with those rows (and the I/D queues) in registers: per 15 scores a window
+// then loads 6 + 15 + 10 + 5 + 15 (gap-open-2 sources, always from memory) ... see DESIGN.md section 4.
+constexpr int CHAIN_MAX = AWV_CHAIN_MAX;
+constexpr int MSTEPS = 16;  // most steps one pass can cover (a lane table entry per step and per source)
+static_assert(TMAX >= 2 && TMAX <= 8 && TMAX * CHAIN_MAX <= MSTEPS - 1, "pass length");
 
 struct MultiPlan {
-  int Tn;                    // steps in this pass
-  int lo[TMAX], hi[TMAX];    // predicted hull of step t (score s0 + 1 + t); lo > hi: empty
+  int Tn;                    // steps in this pass = TMAX-step sweeps * nh (the last sweep may be shorter only when nh == 1)
+  int nh;                    // sweeps chained in this pass
+  int halo;                  // unproductive lanes on either side of a window = ceil(Tn / 4)
   int lo_min, hi_max;        // union of the step hulls
   int vlo, vhi;              // VGPR: lane r = source r's stored hull as lane-aligned columns (empty: BIG / -BIG)
+  int vslo, vshi;            // VGPR: lane t = predicted hull of step t (score s0 + 1 + t) in diagonals; lo > hi: empty
   int int_lo, int_hi;        // window origins whose 64 lane vectors lie inside every source's stored hull
   int end_comp, end_col;     // base case: component and column of the end cell (k = tlen - plen); end_col < 0: no termination test
 };
 
-// source r of a pass that starts after score s0: which component at which score
+// source r of a pass that starts after score s0: which component at which score.  Lanes 0 .. NS0-1 are the
+// I/D rows the pass begins with; lane NS0 + 16 w + step is M source w (0: s - x, 1: s - o1 - e1, 2: s - o2 - e2)
+// of step `step`.
 template <bool P2, int E1, int E2>
 __device__ __forceinline__ void multi_source(const DevPenalties& pn, int s0, int r, int& comp, int& score) {
   constexpr int NS0 = 2 * E1 + (P2 ? 2 * E2 : 0);
@@ -943,66 +950,72 @@ __device__ __forceinline__ void multi_source(const DevPenalties& pn, int s0, int
   else if (P2 && r < 2 * E1 + E2) { comp = C_I2; score = s0 - E2 + 1 + (r - 2 * E1); }
   else if (P2 && r < NS0) { comp = C_D2; score = s0 - E2 + 1 + (r - 2 * E1 - E2); }
   else {
-    constexpr int NT = P2 ? 3 : 2;
-    const int t = (r - NS0) / NT, w = (r - NS0) % NT;
+    const int w = (r - NS0) >> 4, step = (r - NS0) & 15;
     comp = C_M;
-    score = s0 + 1 + t - (w == 0 ? pn.x : w == 1 ? pn.o1 + pn.e1 : pn.o2 + pn.e2);
+    score = s0 + 1 + step - (w == 0 ? pn.x : w == 1 ? pn.o1 + pn.e1 : pn.o2 + pn.e2);
   }
 }
 
 template <bool P2, typename OffT, int E1, int E2, bool BASE>
-__device__ __forceinline__ void plan_multi(const KParams& kp, const Lds<OffT>& lds, const SubCtx& cx, int dir, int s0, int Tn, MultiPlan& mp) {
+__device__ __forceinline__ void plan_multi(const KParams& kp, const Lds<OffT>& lds, const SubCtx& cx, int dir, int s0, int Tn, int nh, MultiPlan& mp) {
   constexpr int NS0 = 2 * E1 + (P2 ? 2 * E2 : 0);
   constexpr int NT = P2 ? 3 : 2;
+  static_assert(NS0 + 16 * NT <= 64, "one lane per source");
   const DevPenalties& pn = kp.pen;
   const int kmin = dir ? cx.kmin[1] : cx.kmin[0];
+  const int lane = threadIdx.x & 63;
   mp.Tn = Tn;
+  mp.nh = nh;
+  mp.halo = (Tn + 3) >> 2;
   mp.lo_min = K_BIG;
   mp.hi_max = -K_BIG;
   mp.end_comp = C_M;
   mp.end_col = -1;
-#pragma unroll
-  for (int t = 0; t < TMAX; ++t) {
-    mp.lo[t] = 1;
-    mp.hi[t] = 0;
-    if (t < Tn) {  // (uniform) the predicted metadata of step t is in LDS before step t + 1 is planned
-      StepPlan pl;
-      plan_step<P2, BASE, OffT>(kp, lds, dir, s0 + 1 + t, pl);
-      mp.lo[t] = pl.lo;
-      mp.hi[t] = pl.hi;
-      if (pl.lo <= pl.hi) {
-        mp.lo_min = min(mp.lo_min, pl.lo);
-        mp.hi_max = max(mp.hi_max, pl.hi);
-      }
+  mp.vslo = 1;
+  mp.vshi = 0;
+  for (int t = 0; t < Tn; ++t) {  // (uniform) the predicted metadata of step t is in LDS before step t + 1 is planned
+    StepPlan pl;
+    plan_step<P2, BASE, OffT>(kp, lds, dir, s0 + 1 + t, pl);
+    if (lane == t) { mp.vslo = pl.lo; mp.vshi = pl.hi; }
+    if (pl.lo <= pl.hi) {
+      mp.lo_min = min(mp.lo_min, pl.lo);
+      mp.hi_max = max(mp.hi_max, pl.hi);
     }
   }
   // every source row's stored extent = the hull of the step that wrote it (its M row's metadata), fetched by
   // lane r in one LDS round trip.  Score 0 is special -- the search's origin: one cell in the begin
   // component's row, nothing stored for the others -- so there the component's own range counts; rows
-  // of negative scores do not exist.
-  const int lane = threadIdx.x & 63;
-  const int ns = NS0 + NT * Tn;
+  // of negative scores do not exist.  (Sources that a chained sweep takes from registers are never looked up.)
   int comp, score;
   multi_source<P2, E1, E2>(pn, s0, lane, comp, score);
+  const bool used = lane < NS0 || (lane < NS0 + 16 * NT && ((lane - NS0) & 15) < Tn);
   RowMeta h = ROW_EMPTY;
-  if (lane < ns && score >= 0)
+  if (used && score >= 0)
     h = meta_load(&lds.ring_meta[(dir * NCOMP + (score == 0 ? comp : C_M)) * kp.ring + (score & (kp.ring - 1))]);
   const bool empty = h.lo > h.hi;
   mp.vlo = empty ? K_BIG : ((h.lo - kmin) & ~3);
   mp.vhi = empty ? -K_BIG : ((h.hi - kmin) | 3);
-  mp.int_lo = wave_max_i32(lane < ns ? mp.vlo : INT_MIN);
-  mp.int_hi = -wave_max_i32(lane < ns ? -mp.vhi : INT_MIN) - 255;
+  // (a chained pass leaves out what it never loads: M source 0 beyond the first sweep, source 1 beyond the second)
+  bool counted = used;
+  if (nh > 1 && lane >= NS0) {
+    const int w = (lane - NS0) >> 4, step = (lane - NS0) & 15;
+    if ((w == 0 && step >= TMAX) || (w == 1 && step >= 2 * TMAX)) counted = false;
+  }
+  mp.int_lo = wave_max_i32(counted ? mp.vlo : INT_MIN);
+  mp.int_hi = -wave_max_i32(counted ? -mp.vhi : INT_MIN) - 255;
 }
 
 // One pass: Tn steps of one direction over all windows of the rows.  Returns the number of cells.
 // BASE: the base case's plain WFA (rows indexed by score in the history arena; every step also stores its I/D
 // rows -- the backtrace reads them -- and tells whether the end cell has been reached).
-template <bool P2, typename OffT, int E1, int E2, bool BASE>
+// CHAIN: the pass may consist of several sweeps per window (mp.nh > 1); needs TMAX == x and 2 TMAX == o1 + e1.
+template <bool P2, typename OffT, int E1, int E2, bool BASE, bool CHAIN>
 __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh, const Lds<OffT>& lds, const SubCtx& cx, rsrc_t rs,
-                                                  int dir, int s0, const MultiPlan& mp, Acc& acc, unsigned& ext_iters) {
+                                                  int dir, int s0, const MultiPlan& mp, Acc& acc, int* maxak_out, unsigned& ext_iters) {
   constexpr bool DEEP = BASE;  // every step's I/D rows go to memory
   static_assert(sizeof(OffT) == 2, "multi-step windows: 16-bit rows");
   static_assert(E1 >= 1 && E1 <= 2 && E2 >= 1 && E2 <= 2, "register-resident I/D depth");
+  static_assert(!(BASE && CHAIN), "the base case runs single sweeps");
   constexpr int NWAVES = WG / 64;
   constexpr int VEC = 4, ESZ = 2;
   constexpr int NS0 = 2 * E1 + (P2 ? 2 * E2 : 0);
@@ -1012,7 +1025,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
   const int lane = threadIdx.x & 63;
   const int kmin = dir ? cx.kmin[1] : cx.kmin[0];
   const int plen = cx.plen, tlen = cx.tlen;
-  const int Tn = mp.Tn;
+  const int Tn = mp.Tn, nh = CHAIN ? mp.nh : 1;
   if (mp.lo_min > mp.hi_max) return 0;  // all steps empty
   if (mp.lo_min - kmin < 256 + 1 || mp.hi_max - kmin + 256 + VEC + 2 > cx.wcols) {
     sh.error = ST_CAPACITY;
@@ -1020,10 +1033,9 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
   }
   const int colLoMin = mp.lo_min - kmin, colHiMax = mp.hi_max - kmin;
   const unsigned nullw = ((unsigned)(unsigned short)NULL16) * 0x00010001u;
-  const bool productive = lane >= MHALO && lane < 64 - MHALO;
-  int lane_maxak[TMAX];
-#pragma unroll
-  for (int t = 0; t < TMAX; ++t) lane_maxak[t] = 0;
+  const int halo = mp.halo;                 // unproductive lanes on either side: their columns go invalid one per step
+  const int stride = (64 - 2 * halo) * VEC;  // new columns per window
+  const bool productive = lane >= halo && lane < 64 - halo;
   bool lane_oob = false;
   unsigned reach_mask = 0;  // BASE: bit t = the end cell has been reached at step t (uniform)
   typedef short s2 __attribute__((ext_vector_type(2)));
@@ -1045,25 +1057,29 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
     w2[1] = v.w[1];
     __builtin_amdgcn_raw_buffer_store_b64(w2, rs, voff, soff, 0);
   };
-  for (int cb = (colLoMin & ~(VEC - 1)) - MHALO * VEC + (NWAVES > 1 ? (int)(threadIdx.x >> 6) * MSTRIDE : 0); cb + MHALO * VEC <= colHiMax;
-       cb += MSTRIDE * NWAVES) {
+  int nwin = 0;
+  for (int cb = (colLoMin & ~(VEC - 1)) - halo * VEC + (NWAVES > 1 ? (int)(threadIdx.x >> 6) * stride : 0); cb + halo * VEC <= colHiMax;
+       cb += stride * NWAVES) {
+    ++nwin;
     const int c0 = cb + lane * VEC;
     const int k0 = c0 + kmin;
     const int voff = c0 * ESZ;
     const bool interior = cb >= mp.int_lo && cb <= mp.int_hi;  // wave-uniform
-    // lanes that can matter: everything that lies inside some source's stored hull is within HALO lanes of the final hull
-    const bool load_on = c0 + (MHALO + 2) * VEC > colLoMin && c0 - (MHALO + 1) * VEC <= colHiMax;
-    // ---- all row loads of the pass, back to back
+    // lanes that can matter: everything that lies inside some source's stored hull is within `halo` lanes of the final hull
+    const bool load_on = c0 + (halo + 2) * VEC > colLoMin && c0 - (halo + 1) * VEC <= colHiMax;
+    auto lmask = [&](int r, V& v) {  // edge windows: lane vectors outside the hull of a source's step hold nothing (or stale data)
+      const int alo = __builtin_amdgcn_readlane(mp.vlo, r), ahi = __builtin_amdgcn_readlane(mp.vhi, r);
+      const bool keep = c0 >= alo && c0 <= ahi;
+      v.w[0] = keep ? v.w[0] : nullw;
+      v.w[1] = keep ? v.w[1] : nullw;
+    };
     const unsigned long long tm0 = PROF_NOW();
-    V qI1[E1], qD1[E1], qI2[E2], qD2[E2], tap[TMAX][NT];
+    // ---- the I/D rows the pass begins with
+    V qI1[E1], qD1[E1], qI2[E2], qD2[E2];
 #pragma unroll
     for (int j = 0; j < E1; ++j) { qI1[j] = V{}; qD1[j] = V{}; }
 #pragma unroll
     for (int j = 0; j < E2; ++j) { qI2[j] = V{}; qD2[j] = V{}; }
-#pragma unroll
-    for (int t = 0; t < TMAX; ++t)
-#pragma unroll
-      for (int w = 0; w < NT; ++w) tap[t][w] = V{};
     if (load_on) {
 #pragma unroll
       for (int j = 0; j < E1; ++j) {
@@ -1077,193 +1093,187 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           qD2[j] = buf_load_raw<OffT, 2>(rs, voff, row_off<BASE, OffT>(kp, dir, C_D2, s0 - E2 + 1 + j));
         }
       }
-#pragma unroll
-      for (int t = 0; t < TMAX; ++t) {
-        if (t < Tn) {
-          tap[t][0] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, s0 + 1 + t - pn.x));
-          tap[t][1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, s0 + 1 + t - pn.o1 - pn.e1));
-          if (P2) tap[t][NT - 1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, s0 + 1 + t - pn.o2 - pn.e2));
-        }
-      }
     }
-    if (!interior) {  // edge windows: lane vectors outside the hull of a source's step hold nothing (or stale data)
-      auto lmask = [&](int r, V& v) {
-        const int alo = __builtin_amdgcn_readlane(mp.vlo, r), ahi = __builtin_amdgcn_readlane(mp.vhi, r);
-        const bool keep = c0 >= alo && c0 <= ahi;
-        v.w[0] = keep ? v.w[0] : nullw;
-        v.w[1] = keep ? v.w[1] : nullw;
-      };
+    // the last two sweeps' own M rows (canonical stored form), what the next sweeps read 5 / 10 scores back
+    V Mp1[CHAIN ? TMAX : 1], Mp2[CHAIN ? TMAX : 1];
 #pragma unroll
-      for (int j = 0; j < E1; ++j) { lmask(j, qI1[j]); lmask(E1 + j, qD1[j]); }
-      if (P2) {
-#pragma unroll
-        for (int j = 0; j < E2; ++j) { lmask(2 * E1 + j, qI2[j]); lmask(2 * E1 + E2 + j, qD2[j]); }
-      }
-#pragma unroll
-      for (int t = 0; t < TMAX; ++t) {
-        if (t < Tn) {
-#pragma unroll
-          for (int w = 0; w < NT; ++w) lmask(NS0 + NT * t + w, tap[t][w]);
-        }
-      }
-    }
+    for (int t = 0; t < (CHAIN ? TMAX : 1); ++t) { Mp1[t] = V{}; Mp2[t] = V{}; }
     const int hbase = plen + k0;
-    PROF_DRAIN();
-    PROF_ADD_L(STAT_T_CR_LOAD, tm0);
-    // ---- the steps, in three sweeps.  Within a pass a step's recurrences need the earlier steps' I/D values and
-    // M rows of EARLIER passes only -- never the extended M values of this pass -- so all the DP arithmetic
-    // goes first, then the extension probes of several steps' cells are issued together (one LDS round trip
-    // per group instead of one per step), then the M rows are stored.
-    int32_t mall[TMAX * VEC];  // step t's four M cells: before extension after sweep 1, final after sweep 2
-    const unsigned long long tm1 = PROF_NOW();
+#pragma nounroll
+    for (int h = 0; h < nh; ++h) {
+      const int sb = s0 + h * TMAX;   // this sweep covers scores sb + 1 .. sb + TMAX
+      const int tb = h * TMAX;        // its first step index within the pass
+      const int tn = min(TMAX, Tn - tb);
+      const bool own0 = CHAIN && h >= 1, own1 = CHAIN && h >= 2;  // (uniform) M sources 0 / 1 come from registers
+      // ---- all row loads of the sweep, back to back
+      V tap[TMAX][NT];
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) {
+      for (int t = 0; t < TMAX; ++t)
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) mall[t * VEC + j] = OFF_NULL;
-      if (t < Tn) {
-        const bool lane_on = productive && c0 + VEC > mp.lo[t] - kmin && c0 <= mp.hi[t] - kmin;
-        const V cMx = tap[t][0], cO1 = tap[t][1];
-        const V rO1l = shift_from_left(cO1), rO1r = shift_from_right(cO1);
-        const V rI1 = shift_from_left(qI1[0]), rD1 = shift_from_right(qD1[0]);
-        V rO2l{}, rO2r{}, rI2{}, rD2{};
-        if (P2) {
-          rO2l = shift_from_left(tap[t][NT - 1]);
-          rO2r = shift_from_right(tap[t][NT - 1]);
-          rI2 = shift_from_left(qI2[0]);
-          rD2 = shift_from_right(qD2[0]);
+        for (int w = 0; w < NT; ++w) tap[t][w] = V{};
+      if (load_on) {
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+          if (t < tn) {
+            if (!own0) tap[t][0] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.x));
+            if (!own1) tap[t][1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o1 - pn.e1));
+            if (P2) tap[t][NT - 1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o2 - pn.e2));
+          }
         }
-        V nI1, nD1, nI2{}, nD2{};
+      }
+      if (!interior) {
+        if (h == 0) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const s2 ins1 = __builtin_elementwise_max(as2(rO1l.w[r]), as2(rI1.w[r])) + one;
-          const s2 del1 = __builtin_elementwise_max(as2(rO1r.w[r]), as2(rD1.w[r]));
-          s2 ins = ins1, del = del1;
-          nI1.w[r] = asu(ins1);
-          nD1.w[r] = asu(del1);
+          for (int j = 0; j < E1; ++j) { lmask(j, qI1[j]); lmask(E1 + j, qD1[j]); }
           if (P2) {
-            const s2 ins2 = __builtin_elementwise_max(as2(rO2l.w[r]), as2(rI2.w[r])) + one;
-            const s2 del2 = __builtin_elementwise_max(as2(rO2r.w[r]), as2(rD2.w[r]));
-            ins = __builtin_elementwise_max(ins, ins2);
-            del = __builtin_elementwise_max(del, del2);
-            nI2.w[r] = asu(ins2);
-            nD2.w[r] = asu(del2);
-          }
-          const s2 mm2 = __builtin_elementwise_max(del, __builtin_elementwise_max(as2(cMx.w[r]) + one, ins));
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int mm = (int)mm2[e];
-            const int hmax = clamp_from_m1(hbase + 2 * r + e, tlen);
-            lane_oob |= lane_on && mm > hmax;
-            mall[t * VEC + 2 * r + e] = (mm > hmax || mm < 0 || !lane_on) ? OFF_NULL : mm;
+            for (int j = 0; j < E2; ++j) { lmask(2 * E1 + j, qI2[j]); lmask(2 * E1 + E2 + j, qD2[j]); }
           }
         }
-        if (DEEP && lane_on) {  // this score's I/D rows (canonical form), whole lane vectors over the step's hull
-          V a, b;
-          a.w[0] = canon(nI1.w[0]); a.w[1] = canon(nI1.w[1]);
-          b.w[0] = canon(nD1.w[0]); b.w[1] = canon(nD1.w[1]);
-          st(row_off<BASE, OffT>(kp, dir, C_I1, s0 + 1 + t), voff, a);
-          st(row_off<BASE, OffT>(kp, dir, C_D1, s0 + 1 + t), voff, b);
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+          if (t < tn) {
+            if (!own0) lmask(NS0 + tb + t, tap[t][0]);
+            if (!own1) lmask(NS0 + 16 + tb + t, tap[t][1]);
+            if (P2) lmask(NS0 + 32 + tb + t, tap[t][NT - 1]);
+          }
+        }
+      }
+      PROF_DRAIN();
+      PROF_ADD_L(STAT_T_CR_LOAD, tm0);
+      // ---- the steps
+      V Mnew[CHAIN ? TMAX : 1];
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        if (t < tn) {
+          const unsigned long long tm1 = PROF_NOW();
+          const int lo_t = __builtin_amdgcn_readlane(mp.vslo, tb + t), hi_t = __builtin_amdgcn_readlane(mp.vshi, tb + t);
+          // every lane inside the step's hull computes (the halo lanes' values feed their neighbours and,
+          // chained, the next sweeps); only the productive ones store, count and flag
+          const bool in_hull = c0 + VEC > lo_t - kmin && c0 <= hi_t - kmin;
+          const bool lane_on = productive && in_hull;
+          V cMx = tap[t][0], cO1 = tap[t][1];
+          if (CHAIN) {
+            if (own0) cMx = Mp1[t];
+            if (own1) cO1 = Mp2[t];
+          }
+          const V rO1l = shift_from_left(cO1), rO1r = shift_from_right(cO1);
+          const V rI1 = shift_from_left(qI1[0]), rD1 = shift_from_right(qD1[0]);
+          V rO2l{}, rO2r{}, rI2{}, rD2{};
           if (P2) {
-            a.w[0] = canon(nI2.w[0]); a.w[1] = canon(nI2.w[1]);
-            b.w[0] = canon(nD2.w[0]); b.w[1] = canon(nD2.w[1]);
-            st(row_off<BASE, OffT>(kp, dir, C_I2, s0 + 1 + t), voff, a);
-            st(row_off<BASE, OffT>(kp, dir, C_D2, s0 + 1 + t), voff, b);
+            rO2l = shift_from_left(tap[t][NT - 1]);
+            rO2r = shift_from_right(tap[t][NT - 1]);
+            rI2 = shift_from_left(qI2[0]);
+            rD2 = shift_from_right(qD2[0]);
+          }
+          V nI1, nD1, nI2{}, nD2{};
+          int32_t m[VEC];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const s2 ins1 = __builtin_elementwise_max(as2(rO1l.w[r]), as2(rI1.w[r])) + one;
+            const s2 del1 = __builtin_elementwise_max(as2(rO1r.w[r]), as2(rD1.w[r]));
+            s2 ins = ins1, del = del1;
+            nI1.w[r] = asu(ins1);
+            nD1.w[r] = asu(del1);
+            if (P2) {
+              const s2 ins2 = __builtin_elementwise_max(as2(rO2l.w[r]), as2(rI2.w[r])) + one;
+              const s2 del2 = __builtin_elementwise_max(as2(rO2r.w[r]), as2(rD2.w[r]));
+              ins = __builtin_elementwise_max(ins, ins2);
+              del = __builtin_elementwise_max(del, del2);
+              nI2.w[r] = asu(ins2);
+              nD2.w[r] = asu(del2);
+            }
+            const s2 mm2 = __builtin_elementwise_max(del, __builtin_elementwise_max(as2(cMx.w[r]) + one, ins));
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int mm = (int)mm2[e];
+              const int hmax = clamp_from_m1(hbase + 2 * r + e, tlen);
+              lane_oob |= lane_on && mm > hmax;
+              // (h < k, i.e. a negative pattern position, never occurs in a real wavefront; the halo lanes' stale values
+              // -- which are extended like any other now that chained sweeps read them back -- may hold anything)
+              m[2 * r + e] = (mm > hmax || mm < max(k0 + 2 * r + e, 0) || !in_hull) ? OFF_NULL : mm;
+            }
+          }
+          if (DEEP && lane_on) {  // this score's I/D rows (canonical form), whole lane vectors over the step's hull
+            V a, b;
+            a.w[0] = canon(nI1.w[0]); a.w[1] = canon(nI1.w[1]);
+            b.w[0] = canon(nD1.w[0]); b.w[1] = canon(nD1.w[1]);
+            st(row_off<BASE, OffT>(kp, dir, C_I1, sb + 1 + t), voff, a);
+            st(row_off<BASE, OffT>(kp, dir, C_D1, sb + 1 + t), voff, b);
+            if (P2) {
+              a.w[0] = canon(nI2.w[0]); a.w[1] = canon(nI2.w[1]);
+              b.w[0] = canon(nD2.w[0]); b.w[1] = canon(nD2.w[1]);
+              st(row_off<BASE, OffT>(kp, dir, C_I2, sb + 1 + t), voff, a);
+              st(row_off<BASE, OffT>(kp, dir, C_D2, sb + 1 + t), voff, b);
+            }
+          }
+          if (BASE && mp.end_comp != C_M) {  // end cell in an indel component: has its offset reached the text end?
+            const V& ev = mp.end_comp == C_I1 ? nI1 : mp.end_comp == C_D1 ? nD1 : mp.end_comp == C_I2 ? nI2 : nD2;
+            const int je = mp.end_col - c0;  // element of this lane's vector, if it holds the end column
+            const bool mine = lane_on && je >= 0 && je < VEC;
+            const unsigned w = (je & 2) ? ev.w[1] : ev.w[0];
+            const int val = (je & 1) ? ((int)w >> 16) : (((int)w << 16) >> 16);
+            if (__any(mine && val >= tlen)) reach_mask |= 1u << (tb + t);
+          }
+          PROF_DRAIN();
+          PROF_ADD_L(STAT_T_CR_ALU, tm1);
+          const unsigned long long tm2 = PROF_NOW();
+          extend_cells<OffT>(lds, cx, dir, k0, m, ext_iters);
+          PROF_DRAIN();
+          PROF_ADD_L(STAT_T_CR_EXTEND, tm2);
+          const unsigned long long tm3 = PROF_NOW();
+          if (!BASE) {  // the row's max antidiagonal (productive cells only)
+            int it_maxak = 0;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+              if (lane_on && m[j] >= 0) it_maxak = max(it_maxak, 2 * m[j] - (k0 + j));
+            const int wmax = wave_max_i32(it_maxak);
+            if (lane == 0) atomicMax(&maxak_out[tb + t], wmax);
+          }
+          {  // canonical stored form of the M cells: what goes to memory and what the next sweeps read back
+            int32_t c[4];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) c[j] = (m[j] < 0 ? NULL16 : min(m[j], tlen + 1)) & 0xFFFF;
+            V mv;
+            mv.w[0] = (unsigned)(c[0] | (c[1] << 16));
+            mv.w[1] = (unsigned)(c[2] | (c[3] << 16));
+            if (lane_on) st(row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t), voff, mv);
+            if (CHAIN) Mnew[t] = mv;
+          }
+          if (BASE && mp.end_comp == C_M) {
+            const int je = mp.end_col - c0;
+            const bool mine = lane_on && je >= 0 && je < VEC;
+            const int val = je == 0 ? m[0] : je == 1 ? m[1] : je == 2 ? m[2] : m[3];
+            if (__any(mine && val >= tlen)) reach_mask |= 1u << (tb + t);
+          }
+          PROF_DRAIN();
+          PROF_ADD_L(STAT_T_CR_STORE, tm3);
+          // the I/D rows of this score enter the register queues (oldest first)
+#pragma unroll
+          for (int j = 0; j + 1 < E1; ++j) { qI1[j] = qI1[j + 1]; qD1[j] = qD1[j + 1]; }
+          qI1[E1 - 1] = nI1;
+          qD1[E1 - 1] = nD1;
+          if (P2) {
+#pragma unroll
+            for (int j = 0; j + 1 < E2; ++j) { qI2[j] = qI2[j + 1]; qD2[j] = qD2[j + 1]; }
+            qI2[E2 - 1] = nI2;
+            qD2[E2 - 1] = nD2;
           }
         }
-        if (BASE && mp.end_comp != C_M) {  // end cell in an indel component: has its offset reached the text end?
-          const V& ev = mp.end_comp == C_I1 ? nI1 : mp.end_comp == C_D1 ? nD1 : mp.end_comp == C_I2 ? nI2 : nD2;
-          const int je = mp.end_col - c0;  // element of this lane's vector, if it holds the end column
-          const bool mine = lane_on && je >= 0 && je < VEC;
-          const unsigned w = (je & 2) ? ev.w[1] : ev.w[0];
-          const int val = (je & 1) ? ((int)w >> 16) : (((int)w << 16) >> 16);
-          if (__any(mine && val >= tlen)) reach_mask |= 1u << t;
-        }
-        // the I/D rows of this score enter the register queues (oldest first)
+      }
+      if (CHAIN) {
 #pragma unroll
-        for (int j = 0; j + 1 < E1; ++j) { qI1[j] = qI1[j + 1]; qD1[j] = qD1[j + 1]; }
-        qI1[E1 - 1] = nI1;
-        qD1[E1 - 1] = nD1;
-        if (P2) {
-#pragma unroll
-          for (int j = 0; j + 1 < E2; ++j) { qI2[j] = qI2[j + 1]; qD2[j] = qD2[j + 1]; }
-          qI2[E2 - 1] = nI2;
-          qD2[E2 - 1] = nD2;
-        }
+        for (int t = 0; t < TMAX; ++t) { Mp2[t] = Mp1[t]; Mp1[t] = Mnew[t]; }
       }
     }
-    PROF_DRAIN();
-    PROF_ADD_L(STAT_T_CR_ALU, tm1);
-    const unsigned long long tm2 = PROF_NOW();
-    {  // (steps beyond Tn hold NULL cells: they probe offset 0 and stay NULL)
-      constexpr int G = MEXT_GROUP;  // steps whose probes are in flight together
-#pragma unroll
-      for (int g = 0; g < TMAX; g += G) {
-        if (g < Tn) {
-          constexpr int NG = G * VEC;
-          if (g + G <= TMAX) {
-            int32_t mg[NG];
-#pragma unroll
-            for (int i = 0; i < NG; ++i) mg[i] = mall[g * VEC + i];
-            extend_cells_n<OffT, NG>(lds, cx, dir, k0, mg, ext_iters);
-#pragma unroll
-            for (int i = 0; i < NG; ++i) mall[g * VEC + i] = mg[i];
-          } else {  // the last, shorter group
-            constexpr int NR = (TMAX % G) * VEC > 0 ? (TMAX % G) * VEC : VEC;
-            int32_t mg[NR];
-#pragma unroll
-            for (int i = 0; i < NR; ++i) mg[i] = mall[g * VEC + i];
-            extend_cells_n<OffT, NR>(lds, cx, dir, k0, mg, ext_iters);
-#pragma unroll
-            for (int i = 0; i < NR; ++i) mall[g * VEC + i] = mg[i];
-          }
-        }
-      }
-    }
-    PROF_DRAIN();
-    PROF_ADD_L(STAT_T_CR_EXTEND, tm2);
-    const unsigned long long tm3 = PROF_NOW();
-#pragma unroll
-    for (int t = 0; t < TMAX; ++t) {
-      if (t < Tn) {
-        const bool lane_on = productive && c0 + VEC > mp.lo[t] - kmin && c0 <= mp.hi[t] - kmin;
-        int32_t m[VEC];
-        int it_maxak = 0;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          m[j] = mall[t * VEC + j];
-          if (m[j] >= 0) it_maxak = max(it_maxak, 2 * m[j] - (k0 + j));
-        }
-        lane_maxak[t] = max(lane_maxak[t], it_maxak);
-        if (lane_on) buf_store_vec<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, s0 + 1 + t), m, tlen);
-        if (BASE && mp.end_comp == C_M) {
-          const int je = mp.end_col - c0;
-          const bool mine = lane_on && je >= 0 && je < VEC;
-          const int val = je == 0 ? m[0] : je == 1 ? m[1] : je == 2 ? m[2] : m[3];
-          if (__any(mine && val >= tlen)) reach_mask |= 1u << t;
-        }
-      }
-    }
-    PROF_DRAIN();
-    PROF_ADD_L(STAT_T_CR_STORE, tm3);
     // ---- the pass's last e1 / e2 I/D rows (canonical form, whole lane vectors over their step's hull)
     if (!DEEP) {
       // queue entry j was produced by step Tn - E + j (Tn >= E); its lanes are those of that step's hull
-      auto step_lo = [&](int tj) {
-        int v = 1;
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) v = (t == tj) ? mp.lo[t] : v;
-        return v;
-      };
-      auto step_hi = [&](int tj) {
-        int v = 0;
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) v = (t == tj) ? mp.hi[t] : v;
-        return v;
-      };
 #pragma unroll
       for (int j = 0; j < E1; ++j) {
         const int tj = Tn - E1 + j;
-        const bool on = productive && c0 + VEC > step_lo(tj) - kmin && c0 <= step_hi(tj) - kmin;
+        const int lo_j = __builtin_amdgcn_readlane(mp.vslo, tj), hi_j = __builtin_amdgcn_readlane(mp.vshi, tj);
+        const bool on = productive && c0 + VEC > lo_j - kmin && c0 <= hi_j - kmin;
         if (on) {
           V a, b;
           a.w[0] = canon(qI1[j].w[0]); a.w[1] = canon(qI1[j].w[1]);
@@ -1276,7 +1286,8 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
 #pragma unroll
         for (int j = 0; j < E2; ++j) {
           const int tj = Tn - E2 + j;
-          const bool on = productive && c0 + VEC > step_lo(tj) - kmin && c0 <= step_hi(tj) - kmin;
+          const int lo_j = __builtin_amdgcn_readlane(mp.vslo, tj), hi_j = __builtin_amdgcn_readlane(mp.vshi, tj);
+          const bool on = productive && c0 + VEC > lo_j - kmin && c0 <= hi_j - kmin;
           if (on) {
             V a, b;
             a.w[0] = canon(qI2[j].w[0]); a.w[1] = canon(qI2[j].w[1]);
@@ -1288,16 +1299,12 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
       }
     }
   }
-  if (threadIdx.x == 0) (BASE ? sh.win_base_multi : sh.win_multi) += (unsigned)((colHiMax - ((colLoMin & ~(VEC - 1)) - MHALO * VEC) - MHALO * VEC) / MSTRIDE + 1);
+  if (threadIdx.x == 0) (BASE ? sh.win_base_multi : sh.win_multi) += (unsigned)(nwin * nh);
   int cells = 0;
   const bool woob = __any(lane_oob);
-#pragma unroll
-  for (int t = 0; t < TMAX; ++t) {
-    if (t < Tn) {
-      const int wmax = wave_max_i32(lane_maxak[t]);
-      if (lane == 0) atomicMax(&acc.maxak_t[t], wmax);
-      if (mp.lo[t] <= mp.hi[t]) cells += mp.hi[t] - mp.lo[t] + 1;
-    }
+  for (int t = 0; t < Tn; ++t) {
+    const int lo_t = __builtin_amdgcn_readlane(mp.vslo, t), hi_t = __builtin_amdgcn_readlane(mp.vshi, t);
+    if (lo_t <= hi_t) cells += hi_t - lo_t + 1;
   }
   if (lane == 0 && woob) acc.oob = 1;
   if (BASE && lane == 0 && reach_mask) atomicOr(&acc.reach, (int)reach_mask);
@@ -1317,7 +1324,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
 typedef __attribute__((address_space(3))) Shared* lds_shared_ptr;
 typedef __attribute__((address_space(3))) unsigned char* lds_bytes_ptr;
 constexpr int MP_MARGIN = 0, MP_DISCARD = 1, MP_MET = 2, MP_ERROR = 3;
-template <bool P2, typename OffT, int E1, int E2>
+template <bool P2, typename OffT, int E1, int E2, bool CHAIN>
 __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned dyn_addr, int s0_v, int fmax_v, int rmax_v, int Tn_v, int pass_v) {
   Shared& sh = *(Shared*)(lds_shared_ptr)(uintptr_t)sh_addr;
   unsigned char* dyn_smem = (unsigned char*)(lds_bytes_ptr)(uintptr_t)dyn_addr;
@@ -1371,12 +1378,19 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
   int nsteps = 0, npass = 0, why = MP_MARGIN;
   unsigned long long cells = 0;
   unsigned ext_iters = 0;
+  const int chain_cap = CHAIN ? min(max(uni(pc.chain_max), 1), CHAIN_MAX) : 1;
   for (;;) {
-    // start keeping every I/D row well before the furthest points can meet: the margin is several times
-    // what the two searches advance while `scope` more rows (and one more pass) are computed
+    // Start keeping every I/D row well before the furthest points can meet: the margin is several times what
+    // the two searches advance while `scope` more rows (and one more pass) are computed.  The longest chain
+    // whose own length still fits in front of that margin is taken.
     const int grow = nsteps > 0 ? (arun0 + arun1 - arun_start) / nsteps : 0;
-    const int margin = 256 + 2 * (kp.pen.scope + Tn) * max(grow, 8);
-    if (arun0 + arun1 >= max_antidiagonal - margin) { why = MP_MARGIN; break; }
+    int nh = 0;
+    for (int c = chain_cap; c >= 1; --c) {
+      const int T = c > 1 ? TMAX * c : Tn;
+      if (arun0 + arun1 < max_antidiagonal - (256 + 2 * (kp.pen.scope + T) * max(grow, 8))) { nh = c; break; }
+    }
+    if (nh == 0) { why = MP_MARGIN; break; }
+    const int T = nh > 1 ? TMAX * nh : Tn;
     const int aslot = pass % 3;
     int nc0 = 0, nc1 = 0;
     // (a real loop over the direction: one copy of the pass code; per-direction values are picked by
@@ -1384,9 +1398,9 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
 #pragma nounroll
     for (int dir = 0; dir < 2; ++dir) {
       MultiPlan mp;
-      plan_multi<P2, OffT, E1, E2, false>(kp, lds, cx, dir, sc, Tn, mp);
+      plan_multi<P2, OffT, E1, E2, false>(kp, lds, cx, dir, sc, T, nh, mp);
       Acc& acc = dir ? sh.acc[aslot][1] : sh.acc[aslot][0];
-      const int nc = compute_rows_multi<P2, OffT, E1, E2, false>(kp, sh, lds, cx, rs, dir, sc, mp, acc, ext_iters);
+      const int nc = compute_rows_multi<P2, OffT, E1, E2, false, CHAIN>(kp, sh, lds, cx, rs, dir, sc, mp, acc, dir ? sh.chain_maxak[1] : sh.chain_maxak[0], ext_iters);
       if (dir) nc1 = nc; else nc0 = nc;
     }
     __syncthreads();
@@ -1395,8 +1409,8 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
     cells += (unsigned long long)(nc0 + nc1);
     // the pass's rows become official one score at a time, in WFA2's phase-1 order (A.6): forward, test, reverse, test
     bool met = false;
-    for (int t = 0; t < Tn; ++t) {
-      const int A0 = uni(sh.acc[aslot][0].maxak_t[t]), A1 = uni(sh.acc[aslot][1].maxak_t[t]);
+    for (int t = 0; t < T; ++t) {
+      const int A0 = uni(sh.chain_maxak[0][t]), A1 = uni(sh.chain_maxak[1][t]);
       const int slot = (sc + 1 + t) & rmask;
       lds.bi_A[slot] = A0;
       lds.bi_A[kp.ring + slot] = A1;
@@ -1409,11 +1423,14 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
       rmax = max(rmax, A1);
       if (fmax + rmax >= max_antidiagonal) met = true;
     }
+    __syncthreads();  // everyone has read the pass's maxima
+    if (threadIdx.x < 32) sh.chain_maxak[threadIdx.x >> 4][threadIdx.x & 15] = 0;
     if (threadIdx.x == 0) { acc_reset(sh.acc[(pass + 2) % 3][0]); acc_reset(sh.acc[(pass + 2) % 3][1]); }
+    __syncthreads();  // ... and they are clear before the next pass adds to them
     ++pass;
     ++npass;
-    nsteps += Tn;
-    sc += Tn;
+    nsteps += T;
+    sc += T;
     if (met) { why = MP_MET; break; }
   }
   __syncthreads();  // every thread is past its last look at the accumulators
@@ -1428,6 +1445,7 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
 #pragma unroll
     for (int i = 0; i < 3; ++i) { acc_reset(sh.acc[i][0]); acc_reset(sh.acc[i][1]); }  // whatever the caller's pass counter says next, its slot is clean
   }
+  if (threadIdx.x < 32) sh.chain_maxak[threadIdx.x >> 4][threadIdx.x & 15] = 0;
   atomicAdd(&sh.ext_multi, (unsigned long long)ext_iters);
   __syncthreads();
 }
@@ -1491,10 +1509,10 @@ __device__ __attribute__((noinline)) void base_phase(unsigned sh_addr, unsigned 
     if (sc + Tn > kp.sb_cap) { why = MP_MARGIN; break; }  // the last scores before the capacity bound: step by step (they report CAPACITY themselves)
     const int aslot = pass % 3;
     MultiPlan mp;
-    plan_multi<P2, OffT, E1, E2, true>(kp, lds, cx, 0, sc, Tn, mp);
+    plan_multi<P2, OffT, E1, E2, true>(kp, lds, cx, 0, sc, Tn, 1, mp);
     mp.end_comp = end_comp;
     mp.end_col = end_col;
-    const int nc = compute_rows_multi<P2, OffT, E1, E2, true>(kp, sh, lds, cx, rs, 0, sc, mp, sh.acc[aslot][0], ext_iters);
+    const int nc = compute_rows_multi<P2, OffT, E1, E2, true, false>(kp, sh, lds, cx, rs, 0, sc, mp, sh.acc[aslot][0], nullptr, ext_iters);
     __syncthreads();
     if (uni(sh.error)) { why = MP_ERROR; break; }
     if (uni(sh.acc[aslot][0].oob) != 0) { why = MP_DISCARD; break; }  // the pass assumed untrimmed rows
@@ -1504,8 +1522,10 @@ __device__ __attribute__((noinline)) void base_phase(unsigned sh_addr, unsigned 
     ++npass;
     if (reach) {  // the end cell was reached at the first such step: that score is the penalty
       const int t_end = __builtin_ctz((unsigned)reach);
-      for (int t = 0; t <= t_end; ++t)
-        if (mp.lo[t] <= mp.hi[t]) cells += (unsigned long long)(mp.hi[t] - mp.lo[t] + 1);
+      for (int t = 0; t <= t_end; ++t) {
+        const int lo_t = __builtin_amdgcn_readlane(mp.vslo, t), hi_t = __builtin_amdgcn_readlane(mp.vshi, t);
+        if (lo_t <= hi_t) cells += (unsigned long long)(hi_t - lo_t + 1);
+      }
       sc += t_end + 1;
       why = MP_MET;
       break;
@@ -2096,6 +2116,7 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
     pc.wcap = kp.wcap;
     pc.x = pn.x; pc.o1 = pn.o1; pc.e1 = pn.e1; pc.o2 = pn.o2; pc.e2 = pn.e2;
     pc.lds_meta_bytes = kp.lds_meta_bytes;
+    pc.chain_max = kp.chain_max;
     pc.plen = plen; pc.tlen = tlen;
     pc.kmin[0] = cx.kmin[0]; pc.kmin[1] = cx.kmin[1];
     pc.wcols = cx.wcols;
@@ -2181,18 +2202,20 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
           sc[0] + 1 - (pn.scope - 1) >= 1) {
         // ---- the far-apart phase: all multi-step passes of this search in one call (multi_phase)
         if constexpr (MULTI_BUILD) {
-          if (P2 || pn.e1 == 1) multi_phase<P2, OffT, P2 ? 2 : 1, 1>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
-          else multi_phase<P2, OffT, 2, 1>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
+          // (chained sweeps only where the scores allow them: 2-piece with x = TMAX and o1 + e1 = 2 TMAX, the default set)
+          if (P2) multi_phase<P2, OffT, 2, 1, P2>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
+          else if (pn.e1 == 1) multi_phase<P2, OffT, 1, 1, false>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
+          else multi_phase<P2, OffT, 2, 1, false>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
         }
         PROF_ADD(STAT_T_BI_COMPUTE, tp0);
         const int why = uni(sh.pres.why);
         if (why == MP_ERROR) { rc = uni(sh.error); break; }
         if (why == MP_MET) { rc = BP_RESTART; break; }
+        steps += (long long)(uni(sh.pres.sc) - sc[0]);
         sc[0] = sc[1] = comp[0] = comp[1] = uni(sh.pres.sc);
         fmax = uni(sh.pres.fmax);
         rmax = uni(sh.pres.rmax);
         pass += uni(sh.pres.npass);
-        steps += (long long)uni(sh.pres.npass) * multi_T;
         {
           const unsigned long long c = ((unsigned long long)(unsigned)uni((int)(sh.pres.cells >> 32)) << 32) | (unsigned)uni((int)sh.pres.cells);
           cells += c;
@@ -2319,6 +2342,7 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
   lds.meta_log = reinterpret_cast<RowMeta*>((char*)hist + kp.hist_meta_offset);
   if (tid < STAT_N) lstats[tid] = 0;
   if (tid < 5) sh.prof[tid] = 0;
+  if (tid < 32) sh.chain_maxak[tid >> 4][tid & 15] = 0;
   __syncthreads();
   for (;;) {
     if (tid == 0) {

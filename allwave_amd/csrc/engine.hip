@@ -314,8 +314,14 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   if (dp.two_piece) multi_T = std::min(multi_T, dp.o2 + dp.e2);
   if (dp.two_piece ? (dp.e1 != 2 || dp.e2 != 1) : (dp.e1 != 1 && dp.e1 != 2)) multi_T = 0;
   if (multi_T < 2 || (e->cfg.flags & AWV_F_SINGLE_STEP)) multi_T = 0;
+  // chained sweeps (compute_rows_multi, CHAIN): the previous one / two sweeps' M rows are this sweep's sources 5 and 10
+  // scores back -- only with x = TMAX and o1 + e1 = 2 TMAX (the default scores); the third source must still come from
+  // earlier passes: TMAX * chain_max <= o2 + e2
+  int chain_max = 1;
+  if (multi_T == awv::TMAX && dp.two_piece && dp.x == awv::TMAX && dp.o1 + dp.e1 == 2 * awv::TMAX && !(e->cfg.flags & AWV_F_NO_CHAIN))
+    chain_max = std::max(1, std::min(awv::CHAIN_MAX, (dp.o2 + dp.e2) / awv::TMAX));
   int ring = 4;
-  while (ring < dp.scope + 2 + (multi_T > 0 ? multi_T - 1 : 0)) ring *= 2;
+  while (ring < dp.scope + 2 + (multi_T > 0 ? multi_T * chain_max - 1 : 0)) ring *= 2;
   const int64_t max_batch = e->cfg.max_batch_pairs > 0 ? e->cfg.max_batch_pairs : (int64_t)1 << 20;
   uint64_t max_arena = e->cfg.max_arena_bytes > 0 ? (uint64_t)e->cfg.max_arena_bytes : (uint64_t)8 << 30;
   // Experiment knobs read from the environment exist only in a -DAWV_DEBUG_KNOBS build; the product library's
@@ -566,6 +572,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       kp.pen = dp;
       kp.ring = ring;
       kp.multi_T = multi_T;
+      kp.chain_max = chain_max;
       kp.wcap = wc;
       kp.ring_mem = e->ring_mem.p;
       kp.ring_slot_stride = ring_stride;

@@ -80,6 +80,7 @@ typedef struct {
 #define AWV_F_NO_PACKED_SEQ 4  /* never stage 2-bit packed sequences in LDS (raw-byte probes from HBM only) */
 #define AWV_F_ONE_WAVE 8       /* always one wave per pair (default: four waves per pair for small batches, long sequences and unequal lengths, sixteen for a few very unequal pairs) */
 #define AWV_F_FOUR_WAVES 16    /* always four waves per pair */
+#define AWV_F_NO_CHAIN 128      /* multi-step passes of one sweep only (no chaining of sweeps through registers) */
 #define AWV_F_SINGLE_STEP 64    /* never use multi-step passes (every step stores all five rows; the round-1 kernel path) */
 #define AWV_F_NO_ARENA_PROBE 32 /* take the first ring-arena allocation as it comes (default: allocate up to four candidates and keep the
                                    one a 1 ms traffic probe finds fastest -- worth up to 6 % of kernel time, costs 1-3 s once per engine:
