@@ -1324,6 +1324,16 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
 typedef __attribute__((address_space(3))) Shared* lds_shared_ptr;
 typedef __attribute__((address_space(3))) unsigned char* lds_bytes_ptr;
 constexpr int MP_MARGIN = 0, MP_DISCARD = 1, MP_MET = 2, MP_ERROR = 3;
+// safety margin = BASE + MUL4/4 * (scope + T) * (recent advance per step), in antidiagonal units.  Tuned on config 2
+// (profiles/r02/margin_ab.json): 256 + 2.0 x -> 1926 ms, 26 restarts; 256 + 1.5 x -> 1903 ms, 942 restarts of 979 k searches;
+// 128 + 1.5 x -> 1911 ms, 13 k restarts; 64 + 1.25 x -> 2154 ms, 124 k restarts.
+#ifndef AWV_MARGIN_BASE
+#define AWV_MARGIN_BASE 256
+#endif
+#ifndef AWV_MARGIN_MUL4
+#define AWV_MARGIN_MUL4 6
+#endif
+constexpr int MARGIN_BASE = AWV_MARGIN_BASE, MARGIN_MUL4 = AWV_MARGIN_MUL4;
 template <bool P2, typename OffT, int E1, int E2, bool CHAIN>
 __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned dyn_addr, int s0_v, int fmax_v, int rmax_v, int Tn_v, int pass_v) {
   Shared& sh = *(Shared*)(lds_shared_ptr)(uintptr_t)sh_addr;
@@ -1387,7 +1397,7 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
     int nh = 0;
     for (int c = chain_cap; c >= 1; --c) {
       const int T = c > 1 ? TMAX * c : Tn;
-      if (arun0 + arun1 < max_antidiagonal - (256 + 2 * (kp.pen.scope + T) * max(grow, 8))) { nh = c; break; }
+      if (arun0 + arun1 < max_antidiagonal - (MARGIN_BASE + MARGIN_MUL4 * (kp.pen.scope + T) * max(grow, 8) / 4)) { nh = c; break; }
     }
     if (nh == 0) { why = MP_MARGIN; break; }
     const int T = nh > 1 ? TMAX * nh : Tn;
