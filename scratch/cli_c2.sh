@@ -22,14 +22,3 @@ for mode in "--forward-only" ""; do
   done
 done
 head -c 300 /tmp/c2.paf; echo
-# several batches per call (CIGAR arena capped at 170 MB = 4 batches of config 2): sinks inline vs handed to the helper thread
-for knob in "AWV_INLINE_SINK=1" "AWV_PIPELINED=1"; do
-  for rep in 1 2; do
-    s=$(date +%s.%N)
-    env AWV_MAX_ARENA_MB=170 $knob timeout -k 10 200 ./allwave_amd/allwave_hip -i /tmp/c2.fa -o /tmp/c2b.paf -p none -s 0,5,8,2,24,1 -t 16 --forward-only 2> /tmp/c2.err || { tail -3 /tmp/c2.err; exit 1; }
-    e=$(date +%s.%N)
-    cmp -s /tmp/c2_fwd.paf /tmp/c2b.paf && same=identical || same=DIFFERENT
-    python -c "t=$e-$s; print('cli c2 4 batches $knob run $rep: %.2f s wall, PAF $same to the one-batch run' % t)"
-    grep -E "sink|aligned" /tmp/c2.err | tail -3
-  done
-done

@@ -209,9 +209,9 @@ def test_bad_arguments(engine):
 
 
 def test_row_width_and_sequence_paths_agree(oracle):
-    """The kernel variants must be interchangeable: one wave vs four waves per pair, 16-bit vs forced
-    32-bit wavefront rows, 2-bit packed LDS staging vs raw-byte probes from HBM -- all bit-exact
-    against the oracle."""
+    """The kernel variants must be interchangeable: one wave vs four waves per pair, multi-step passes
+    (chained sweeps / single sweeps) vs the step-by-step path, 16-bit vs forced 32-bit wavefront rows,
+    2-bit packed LDS staging vs raw-byte probes from HBM -- all bit-exact against the oracle."""
     from allwave_amd import ffi
     rng = random.Random(4242)
     seqs, pairs = [], []
@@ -219,7 +219,8 @@ def test_row_width_and_sequence_paths_agree(oracle):
         s, t = random_pair(rng, 2500)
         seqs += [s, t]
         pairs.append((len(seqs) - 2, len(seqs) - 1))
-    for flags in (ffi.AWV_F_ONE_WAVE, ffi.AWV_F_FOUR_WAVES, ffi.AWV_F_ONE_WAVE | ffi.AWV_F_FORCE_INT32,
+    for flags in (ffi.AWV_F_ONE_WAVE, ffi.AWV_F_FOUR_WAVES, ffi.AWV_F_ONE_WAVE | ffi.AWV_F_SINGLE_STEP, ffi.AWV_F_ONE_WAVE | ffi.AWV_F_NO_CHAIN,
+                  ffi.AWV_F_FOUR_WAVES | ffi.AWV_F_SINGLE_STEP, ffi.AWV_F_ONE_WAVE | ffi.AWV_F_FORCE_INT32,
                   ffi.AWV_F_FOUR_WAVES | ffi.AWV_F_FORCE_INT32, ffi.AWV_F_ONE_WAVE | ffi.AWV_F_NO_PACKED_SEQ,
                   ffi.AWV_F_FOUR_WAVES | ffi.AWV_F_NO_PACKED_SEQ, ffi.AWV_F_ONE_WAVE | ffi.AWV_F_FORCE_INT32 | ffi.AWV_F_NO_PACKED_SEQ):
         e = ffi.Engine(flags=flags)
@@ -228,6 +229,39 @@ def test_row_width_and_sequence_paths_agree(oracle):
                 check_against_oracle(e, oracle, seqs, pairs, scores)
         finally:
             e.close()
+
+
+@pytest.mark.parametrize("scores", [DEFAULT_2P, (0, 7, 12, 2, 36, 1), (0, 4, 6, 2, 18, 1), (0, 3, 4, 1), (0, 4, 6, 2), (0, 5, 8, 2, 12, 1)])
+def test_multi_step_passes_all_presets(oracle, scores):
+    """The far-apart phase in multi-step passes under every penalty shape it is instantiated for -- the
+    default (chained sweeps: x = 5, o1+e1 = 10), the CLI's other ANI presets (main.rs:83-124: single sweeps of
+    5 / 4 / 3 scores), gap-affine with e = 2, and a 2-piece set whose second gap opens early (o2+e2 = 13:
+    chains of two) -- on pairs long enough (3-12 kbp, 3-12 %) for the phase to run, including unequal
+    lengths; stats confirm the passes ran, results equal the oracle's and the step-by-step kernel's."""
+    from allwave_amd import ffi
+    rng = random.Random(hash(scores) & 0xFFFF)
+    seqs, pairs = [], []
+    for n, d in ((3000, 0.05), (6000, 0.03), (12000, 0.08), (5000, 0.12), (9000, 0.04)):
+        a = rand_seq(rng, n)
+        b = mutate(a, d, rng)
+        seqs += [a, b, b[: n - n // 7]]
+        k = len(seqs) - 3
+        pairs += [(k, k + 1), (k + 1, k), (k + 2, k), (k, k + 2)]
+    e = ffi.Engine(flags=ffi.AWV_F_ONE_WAVE)
+    try:
+        check_against_oracle(e, oracle, seqs, pairs, scores)
+        st = e.stats()
+        assert st.multi_cell_steps > 0.3 * st.cell_steps, (st.multi_cell_steps, st.cell_steps)
+        res_multi, cig_multi = e.align_pairs(scores, pairs)
+    finally:
+        e.close()
+    e = ffi.Engine(flags=ffi.AWV_F_ONE_WAVE | ffi.AWV_F_SINGLE_STEP)
+    try:
+        res_single, cig_single = e.align_pairs(scores, pairs)
+        assert e.stats().multi_cell_steps == 0
+    finally:
+        e.close()
+    assert (res_multi["penalty"] == res_single["penalty"]).all() and cig_multi == cig_single
 
 
 def test_long_sequences_use_32bit_rows(engine, oracle):

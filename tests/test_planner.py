@@ -285,3 +285,19 @@ def test_cli_end_to_end(host, oracle, tmp_path):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "Kept sequences with prefixes: 4 -> 2" in out.stderr
     assert len((tmp_path / "o.paf").read_text().splitlines()) == 2
+
+
+@pytest.mark.gpu
+def test_cli_reports_write_errors(host, tmp_path):
+    """A PAF that cannot be written must not pass for a complete one: the reference propagates the writer's error
+    (main.rs:355 `writeln!(..)?`, joined at :451-453) and exits non-zero; so does the driver (/dev/full: every
+    write fails with ENOSPC)."""
+    rng = random.Random(12)
+    a = rand_seq(rng, 1500)
+    fa = tmp_path / "in.fa"
+    fa.write_text("".join(">s%d\n%s\n" % (i, mutate(a, 0.03, rng).decode()) for i in range(6)))
+    cli = os.path.join(ROOT, "allwave_amd", "allwave_hip")
+    ok = subprocess.run([cli, "-i", str(fa), "-o", str(tmp_path / "ok.paf"), "-p", "none", "--no-progress"], capture_output=True, timeout=300)
+    assert ok.returncode == 0 and len((tmp_path / "ok.paf").read_text().splitlines()) == 30
+    bad = subprocess.run([cli, "-i", str(fa), "-o", "/dev/full", "-p", "none", "--no-progress"], capture_output=True, timeout=300)
+    assert bad.returncode != 0 and b"write error" in bad.stderr
