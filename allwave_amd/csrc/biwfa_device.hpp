@@ -313,16 +313,23 @@ __device__ __forceinline__ void unpack_raw(const RawVec<OffT>& r, int32_t (&out)
   }
 }
 
+// Canonical 16-bit stored form of two M cells (each either OFF_NULL or an offset >= 0): v < 0 ? NULL16 : min(v, tlen + 1),
+// packed low | high.  One v_med3 per cell (OFF_NULL clamps up to NULL16, an offset past the text end down to tlen + 1)
+// and one v_perm for the pair.
+__device__ __forceinline__ unsigned pack_canon16(int32_t lo, int32_t hi, int tlen1) {
+  int a, b;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(a) : "v"(lo), "v"((int)NULL16), "s"(tlen1));
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(b) : "v"(hi), "v"((int)NULL16), "s"(tlen1));
+  return __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x05040100u);
+}
+
 template <typename OffT>
 __device__ __forceinline__ void buf_store_vec(rsrc_t r, int voff, int soff, const int32_t (&v)[4], int tlen) {
   if (sizeof(OffT) == 2) {
-    int32_t c[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c[j] = (v[j] < 0 ? NULL16 : min(v[j], tlen + 1)) & 0xFFFF;
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     u32x2 raw;
-    raw[0] = (unsigned)(c[0] | (c[1] << 16));
-    raw[1] = (unsigned)(c[2] | (c[3] << 16));
+    raw[0] = pack_canon16(v[0], v[1], tlen + 1);
+    raw[1] = pack_canon16(v[2], v[3], tlen + 1);
     __builtin_amdgcn_raw_buffer_store_b64(raw, r, voff, soff, 0);
   } else {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -769,15 +776,6 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
         mask(pl.src[6], cD2);
       }
     }
-    const RawVec<OffT> rO1l = shift_from_left(cO1), rO1r = shift_from_right(cO1);
-    const RawVec<OffT> rI1 = shift_from_left(cI1), rD1 = shift_from_right(cD1);
-    RawVec<OffT> rO2l{}, rO2r{}, rI2{}, rD2{};
-    if (P2) {
-      rO2l = shift_from_left(cO2);
-      rO2r = shift_from_right(cO2);
-      rI2 = shift_from_left(cI2);
-      rD2 = shift_from_right(cD2);
-    }
     const int hbase = plen + k0;
     if constexpr (sizeof(OffT) == 2) {
       // ---- 16-bit rows: the DP runs on packed pairs (v_pk_max_i16 / v_pk_add_u16 / v_pk_min_i16),
@@ -798,17 +796,30 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
         const s2 c = __builtin_elementwise_min(v, tlen1);
         return __builtin_bit_cast(s2, __builtin_elementwise_min(__builtin_bit_cast(us2, c), null_u));
       };
+      // max first, neighbour shift after: max(O[k-1], I[k-1]) = (max(O, I))[k-1] -- one shift per gap kind instead of two
+      auto pkmax = [&](const RawVec<OffT>& a, const RawVec<OffT>& b) {
+        RawVec<OffT> o;
+        o.w[0] = asu(__builtin_elementwise_max(as2(a.w[0]), as2(b.w[0])));
+        o.w[1] = asu(__builtin_elementwise_max(as2(a.w[1]), as2(b.w[1])));
+        return o;
+      };
+      const RawVec<OffT> sI1 = shift_from_left(pkmax(cO1, cI1)), sD1 = shift_from_right(pkmax(cO1, cD1));
+      RawVec<OffT> sI2{}, sD2{};
+      if (P2) {
+        sI2 = shift_from_left(pkmax(cO2, cI2));
+        sD2 = shift_from_right(pkmax(cO2, cD2));
+      }
       RawVec<OffT> oI1, oD1, oI2, oD2;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const s2 ins1 = __builtin_elementwise_max(as2(rO1l.w[r]), as2(rI1.w[r])) + one;
-        const s2 del1 = __builtin_elementwise_max(as2(rO1r.w[r]), as2(rD1.w[r]));
+        const s2 ins1 = as2(sI1.w[r]) + one;
+        const s2 del1 = as2(sD1.w[r]);
         s2 ins = ins1, del = del1;
         oI1.w[r] = asu(canon(ins1));
         oD1.w[r] = asu(canon(del1));
         if (P2) {
-          const s2 ins2 = __builtin_elementwise_max(as2(rO2l.w[r]), as2(rI2.w[r])) + one;
-          const s2 del2 = __builtin_elementwise_max(as2(rO2r.w[r]), as2(rD2.w[r]));
+          const s2 ins2 = as2(sI2.w[r]) + one;
+          const s2 del2 = as2(sD2.w[r]);
           ins = __builtin_elementwise_max(ins, ins2);
           del = __builtin_elementwise_max(del, del2);
           oI2.w[r] = asu(canon(ins2));
@@ -837,6 +848,15 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
         if (P2) { st(tI2, oI2); st(tD2, oD2); }
       }
     } else {
+      const RawVec<OffT> rO1l = shift_from_left(cO1), rO1r = shift_from_right(cO1);
+      const RawVec<OffT> rI1 = shift_from_left(cI1), rD1 = shift_from_right(cD1);
+      RawVec<OffT> rO2l{}, rO2r{}, rI2{}, rD2{};
+      if (P2) {
+        rO2l = shift_from_left(cO2);
+        rO2r = shift_from_right(cO2);
+        rI2 = shift_from_left(cI2);
+        rD2 = shift_from_right(cD2);
+      }
       int32_t ins1[VEC], del1[VEC], ins2[VEC], del2[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -1037,6 +1057,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
   const int stride = (64 - 2 * halo) * VEC;  // new columns per window
   const bool productive = lane >= halo && lane < 64 - halo;
   bool lane_oob = false;
+  int lane_maxak = 0;       // max antidiagonal over all of the pass's productive cells
   unsigned reach_mask = 0;  // BASE: bit t = the end cell has been reached at step t (uniform)
   typedef short s2 __attribute__((ext_vector_type(2)));
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -1157,27 +1178,31 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             if (own0) cMx = Mp1[t];
             if (own1) cO1 = Mp2[t];
           }
-          const V rO1l = shift_from_left(cO1), rO1r = shift_from_right(cO1);
-          const V rI1 = shift_from_left(qI1[0]), rD1 = shift_from_right(qD1[0]);
-          V rO2l{}, rO2r{}, rI2{}, rD2{};
+          // max first, neighbour shift after: max(O[k-1], I[k-1]) = (max(O, I))[k-1] -- one shift per gap kind instead of two
+          auto pkmax = [&](const V& a, const V& b) {
+            V o;
+            o.w[0] = asu(__builtin_elementwise_max(as2(a.w[0]), as2(b.w[0])));
+            o.w[1] = asu(__builtin_elementwise_max(as2(a.w[1]), as2(b.w[1])));
+            return o;
+          };
+          const V sI1 = shift_from_left(pkmax(cO1, qI1[0])), sD1 = shift_from_right(pkmax(cO1, qD1[0]));
+          V sI2{}, sD2{};
           if (P2) {
-            rO2l = shift_from_left(tap[t][NT - 1]);
-            rO2r = shift_from_right(tap[t][NT - 1]);
-            rI2 = shift_from_left(qI2[0]);
-            rD2 = shift_from_right(qD2[0]);
+            sI2 = shift_from_left(pkmax(tap[t][NT - 1], qI2[0]));
+            sD2 = shift_from_right(pkmax(tap[t][NT - 1], qD2[0]));
           }
           V nI1, nD1, nI2{}, nD2{};
           int32_t m[VEC];
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
-            const s2 ins1 = __builtin_elementwise_max(as2(rO1l.w[r]), as2(rI1.w[r])) + one;
-            const s2 del1 = __builtin_elementwise_max(as2(rO1r.w[r]), as2(rD1.w[r]));
+            const s2 ins1 = as2(sI1.w[r]) + one;
+            const s2 del1 = as2(sD1.w[r]);
             s2 ins = ins1, del = del1;
             nI1.w[r] = asu(ins1);
             nD1.w[r] = asu(del1);
             if (P2) {
-              const s2 ins2 = __builtin_elementwise_max(as2(rO2l.w[r]), as2(rI2.w[r])) + one;
-              const s2 del2 = __builtin_elementwise_max(as2(rO2r.w[r]), as2(rD2.w[r]));
+              const s2 ins2 = as2(sI2.w[r]) + one;
+              const s2 del2 = as2(sD2.w[r]);
               ins = __builtin_elementwise_max(ins, ins2);
               del = __builtin_elementwise_max(del, del2);
               nI2.w[r] = asu(ins2);
@@ -1222,21 +1247,15 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           PROF_DRAIN();
           PROF_ADD_L(STAT_T_CR_EXTEND, tm2);
           const unsigned long long tm3 = PROF_NOW();
-          if (!BASE) {  // the row's max antidiagonal (productive cells only)
-            int it_maxak = 0;
+          if (!BASE) {  // the pass's max antidiagonal (productive cells only), reduced once after the last window
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
-              if (lane_on && m[j] >= 0) it_maxak = max(it_maxak, 2 * m[j] - (k0 + j));
-            const int wmax = wave_max_i32(it_maxak);
-            if (lane == 0) atomicMax(&maxak_out[tb + t], wmax);
+              if (lane_on && m[j] >= 0) lane_maxak = max(lane_maxak, 2 * m[j] - (k0 + j));
           }
           {  // canonical stored form of the M cells: what goes to memory and what the next sweeps read back
-            int32_t c[4];
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) c[j] = (m[j] < 0 ? NULL16 : min(m[j], tlen + 1)) & 0xFFFF;
             V mv;
-            mv.w[0] = (unsigned)(c[0] | (c[1] << 16));
-            mv.w[1] = (unsigned)(c[2] | (c[3] << 16));
+            mv.w[0] = pack_canon16(m[0], m[1], tlen + 1);
+            mv.w[1] = pack_canon16(m[2], m[3], tlen + 1);
             if (lane_on) st(row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t), voff, mv);
             if (CHAIN) Mnew[t] = mv;
           }
@@ -1307,6 +1326,10 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
     if (lo_t <= hi_t) cells += hi_t - lo_t + 1;
   }
   if (lane == 0 && woob) acc.oob = 1;
+  if (!BASE) {
+    const int wmax = wave_max_i32(lane_maxak);
+    if (lane == 0) atomicMax(&maxak_out[0], wmax);
+  }
   if (BASE && lane == 0 && reach_mask) atomicOr(&acc.reach, (int)reach_mask);
   return cells;
 }
@@ -1417,22 +1440,24 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
     if (uni(sh.error)) { why = MP_ERROR; break; }
     if (uni(sh.acc[aslot][0].oob) != 0 || uni(sh.acc[aslot][1].oob) != 0) { why = MP_DISCARD; break; }  // the pass assumed untrimmed rows
     cells += (unsigned long long)(nc0 + nc1);
-    // the pass's rows become official one score at a time, in WFA2's phase-1 order (A.6): forward, test, reverse, test
-    bool met = false;
+    // The pass's rows become official.  WFA2's phase-1 order is forward, test, reverse, test per score (A.6), but
+    // the running maxima only grow: some test inside the pass holds exactly when the one after its last score
+    // does -- so one maximum per direction over the whole pass decides it, and no per-score reduction is
+    // needed.  (The per-score entries written below are that upper bound: the overlap search never looks at a
+    // pass's scores -- they lie before `deep_since` -- and a bound could only make its row filter scan more.)
+    const int P0 = uni(sh.chain_maxak[0][0]), P1 = uni(sh.chain_maxak[1][0]);
     for (int t = 0; t < T; ++t) {
-      const int A0 = uni(sh.chain_maxak[0][t]), A1 = uni(sh.chain_maxak[1][t]);
       const int slot = (sc + 1 + t) & rmask;
-      lds.bi_A[slot] = A0;
-      lds.bi_A[kp.ring + slot] = A1;
+      lds.bi_A[slot] = P0;
+      lds.bi_A[kp.ring + slot] = P1;
       lds.bi_oob[slot] = 0;
       lds.bi_oob[kp.ring + slot] = 0;
-      arun0 = max(arun0, A0);
-      arun1 = max(arun1, A1);
-      fmax = max(fmax, A0);
-      if (fmax + rmax >= max_antidiagonal) met = true;
-      rmax = max(rmax, A1);
-      if (fmax + rmax >= max_antidiagonal) met = true;
     }
+    arun0 = max(arun0, P0);
+    arun1 = max(arun1, P1);
+    fmax = max(fmax, P0);
+    rmax = max(rmax, P1);
+    const bool met = fmax + rmax >= max_antidiagonal;
     __syncthreads();  // everyone has read the pass's maxima
     if (threadIdx.x < 32) sh.chain_maxak[threadIdx.x >> 4][threadIdx.x & 15] = 0;
     if (threadIdx.x == 0) { acc_reset(sh.acc[(pass + 2) % 3][0]); acc_reset(sh.acc[(pass + 2) % 3][1]); }

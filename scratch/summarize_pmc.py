@@ -49,8 +49,7 @@ out = {
     "vmem_wr_insts_per_cell_step": ctr["SQ_INSTS_VMEM_WR"] / cells,
     "wave_wait_fraction": ctr["SQ_WAIT_ANY"] / max(ctr["SQ_WAVE_CYCLES"], 1),
     "wave_active_fraction": ctr["SQ_ACTIVE_INST_ANY"] / max(ctr["SQ_WAVE_CYCLES"], 1),
-    "valu_frac_quadcycle_formula": ctr["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * kcyc),
-    "valu_frac_at_measured_issue_cost": ctr["SQ_INSTS_VALU"] * 1.4 / (1024 * kcyc),
+    "valu_frac": ctr["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * kcyc),  # quad-cycles x 4 / (1024 SIMDs x kernel cycles at 2.4 GHz)
     "ta_addr_fifo_full_fraction_of_cu_cycles": ctr["SQ_VMEM_TA_ADDR_FIFO_FULL"] / max(ctr["SQ_BUSY_CU_CYCLES"], 1),
 }
 json.dump(out, open(os.path.join(pr, "pmc_bench_c2.json"), "w"), indent=1)

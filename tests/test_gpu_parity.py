@@ -257,6 +257,7 @@ def test_multi_step_passes_all_presets(oracle, scores):
         e.close()
     e = ffi.Engine(flags=ffi.AWV_F_ONE_WAVE | ffi.AWV_F_SINGLE_STEP)
     try:
+        e.set_sequences(seqs)
         res_single, cig_single = e.align_pairs(scores, pairs)
         assert e.stats().multi_cell_steps == 0
     finally:
