@@ -316,11 +316,14 @@ __device__ __forceinline__ void unpack_raw(const RawVec<OffT>& r, int32_t (&out)
 // Canonical 16-bit stored form of two M cells (each either OFF_NULL or an offset >= 0): v < 0 ? NULL16 : min(v, tlen + 1),
 // packed low | high.  One v_med3 per cell (OFF_NULL clamps up to NULL16, an offset past the text end down to tlen + 1)
 // and one v_perm for the pair.
+__device__ __forceinline__ unsigned pack_canon16(int32_t lo, int32_t hi, int tlen1, int& clo, int& chi) {
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(clo) : "v"(lo), "v"((int)NULL16), "s"(tlen1));
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(chi) : "v"(hi), "v"((int)NULL16), "s"(tlen1));
+  return __builtin_amdgcn_perm((unsigned)chi, (unsigned)clo, 0x05040100u);
+}
 __device__ __forceinline__ unsigned pack_canon16(int32_t lo, int32_t hi, int tlen1) {
   int a, b;
-  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(a) : "v"(lo), "v"((int)NULL16), "s"(tlen1));
-  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(b) : "v"(hi), "v"((int)NULL16), "s"(tlen1));
-  return __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x05040100u);
+  return pack_canon16(lo, hi, tlen1, a, b);
 }
 
 template <typename OffT>
@@ -583,7 +586,10 @@ __device__ __forceinline__ RawVec<int32_t> shift_from_right(const RawVec<int32_t
 // extend (A.4) of N = 4 * steps M cells of one lane (cell i lies on diagonal k0 + i % 4; m[i] < 0: NULL, left
 // alone): the first probe (16 bases) of all N cells is issued together -- one LDS round trip for the lot,
 // invalid cells probe offset 0, always readable -- then the few longer runs continue in a loop each
-template <typename OffT, int N>
+// PERCELL: the rare longer runs branch per cell on the lanes' condition itself instead of through a per-lane bit mask
+// (fewer vector instructions; used by the multi-step passes -- in the step-by-step loop, whose register file is full,
+// the grouped form keeps the allocation it has)
+template <typename OffT, int N, bool PERCELL = false>
 __device__ __forceinline__ void extend_cells_n(const Lds<OffT>& lds, const SubCtx& cx, int dir, int k0, int32_t (&m)[N], unsigned& ext_iters) {
   static_assert(N % 4 == 0 && N <= 32, "whole lane vectors");
   const gseq_t Pp = dir ? cx.P[1] : cx.P[0];  // (selects: `dir` may be a run-time value, SubCtx lives in registers)
@@ -609,6 +615,19 @@ __device__ __forceinline__ void extend_cells_n(const Lds<OffT>& lds, const SubCt
     } else {
 #pragma unroll
       for (int j = 0; j < N; ++j) nn[j] = packed_first_count<1>(seq, cx, vv[j], hh[j]);
+    }
+    if (PERCELL) {
+      ext_iters += N;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const bool more = nn[j] == PROBE_FIRST && rr[j] > PROBE_FIRST;
+        m[j] += min(nn[j], rr[j]);  // rr == 0 for NULL cells: unchanged
+        if (more) {
+          const int v = m[j] - (k0 + (j & 3)), h = m[j];
+          m[j] += dir == 0 ? extend_lcp_packed<0>(seq, cx, v, h, ext_iters) : extend_lcp_packed<1>(seq, cx, v, h, ext_iters);
+        }
+      }
+      return;
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -1243,19 +1262,22 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           PROF_DRAIN();
           PROF_ADD_L(STAT_T_CR_ALU, tm1);
           const unsigned long long tm2 = PROF_NOW();
-          extend_cells<OffT>(lds, cx, dir, k0, m, ext_iters);
+          extend_cells_n<OffT, 4, true>(lds, cx, dir, k0, m, ext_iters);
           PROF_DRAIN();
           PROF_ADD_L(STAT_T_CR_EXTEND, tm2);
           const unsigned long long tm3 = PROF_NOW();
-          if (!BASE) {  // the pass's max antidiagonal (productive cells only), reduced once after the last window
-#pragma unroll
-            for (int j = 0; j < VEC; ++j)
-              if (lane_on && m[j] >= 0) lane_maxak = max(lane_maxak, 2 * m[j] - (k0 + j));
-          }
           {  // canonical stored form of the M cells: what goes to memory and what the next sweeps read back
             V mv;
-            mv.w[0] = pack_canon16(m[0], m[1], tlen + 1);
-            mv.w[1] = pack_canon16(m[2], m[3], tlen + 1);
+            int c[VEC];
+            mv.w[0] = pack_canon16(m[0], m[1], tlen + 1, c[0], c[1]);
+            mv.w[1] = pack_canon16(m[2], m[3], tlen + 1, c[2], c[3]);
+            if (!BASE) {
+              // the pass's max antidiagonal, reduced once after the last window.  From the clamped values: a NULL is
+              // -16384 there, so 2 c - k stays far below any real antidiagonal without a test per cell; cells outside
+              // the step's hull are NULL, and the halo lanes' sums are dropped at the end.
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) lane_maxak = max(lane_maxak, (c[j] - (k0 + j)) + c[j]);
+            }
             if (lane_on) st(row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t), voff, mv);
             if (CHAIN) Mnew[t] = mv;
           }
@@ -1327,7 +1349,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
   }
   if (lane == 0 && woob) acc.oob = 1;
   if (!BASE) {
-    const int wmax = wave_max_i32(lane_maxak);
+    const int wmax = wave_max_i32(productive ? lane_maxak : 0);
     if (lane == 0) atomicMax(&maxak_out[0], wmax);
   }
   if (BASE && lane == 0 && reach_mask) atomicOr(&acc.reach, (int)reach_mask);
