@@ -16,6 +16,17 @@ lens = (offs[1:] - offs[:-1]).astype(np.int64)
 seqs = [bytes(data[offs[i]:offs[i + 1]]) for i in range(cfg["nseq"])]
 pairs = np.asarray(H.plan_pairs(ids, seqs, cfg["sparsify"]), dtype=np.int32).reshape(-1, 2)
 del seqs
+sel = sys.argv[4] if len(sys.argv) > 4 else "all"   # all | rows16 | rows32 | shorttext (tlen < 32760 <= plen) | shortpattern
+ql, tl = lens[pairs[:, 0]], lens[pairs[:, 1]]
+if sel == "rows16":
+    pairs = pairs[(ql < 32760) & (tl < 32760)]
+elif sel == "rows32":
+    pairs = pairs[(ql >= 32760) | (tl >= 32760)]
+elif sel == "shorttext":
+    pairs = pairs[(ql >= 32760) & (tl < 32760)]
+elif sel == "shortpattern":
+    pairs = pairs[(ql < 32760) & (tl >= 32760)]
+pairs = np.ascontiguousarray(pairs)
 e = ffi.Engine(flags=flags | ffi.AWV_F_KEEP_ON_DEVICE)
 e.set_sequences((data, offs))
 t0 = time.time()
@@ -26,7 +37,7 @@ ok = (res["status"] == 0) & (res["q_end"] == lens[pairs[:, 0]]) & (res["t_end"] 
      (res["num_matches"] + res["num_mismatches"] + res["num_ins"] + res["num_del"] == res["cigar_len"])
 bp = int(lens[pairs[:, 0]].sum())
 esz = 2  # bytes per row element where both lengths fit 16 bits; quoted per cell-step below at the 16-bit size
-print(json.dumps({"config": name, "pairs": len(pairs), "failed_invariants": int((~ok).sum()), "wall_s": round(wall, 2), "kernel_ms": round(st.kernel_ms, 1),
+print(json.dumps({"config": name, "select": sel, "pairs": len(pairs), "failed_invariants": int((~ok).sum()), "wall_s": round(wall, 2), "kernel_ms": round(st.kernel_ms, 1),
                   "launches": st.launches, "Mbp_s_kernel": round(bp / st.kernel_ms / 1e3, 2), "cell_steps": st.cell_steps,
                   "cell_steps_per_s": st.cell_steps / (st.kernel_ms * 1e-3), "multi_frac": round(st.multi_cell_steps / max(st.cell_steps, 1), 4),
                   "restarts": st.restarts}), flush=True)
