@@ -1138,7 +1138,13 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
     V Mp1[CHAIN ? TMAX : 1], Mp2[CHAIN ? TMAX : 1];
 #pragma unroll
     for (int t = 0; t < (CHAIN ? TMAX : 1); ++t) { Mp1[t] = V{}; Mp2[t] = V{}; }
-    const int hbase = plen + k0;
+    // per cell, the largest / smallest offset inside the matrix on its diagonal (the same for every step of the pass)
+    int hmaxv[VEC], hminv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      hmaxv[j] = clamp_from_m1(plen + k0 + j, tlen);
+      hminv[j] = max(k0 + j, 0);
+    }
 #pragma nounroll
     for (int h = 0; h < nh; ++h) {
       const int sb = s0 + h * TMAX;   // this sweep covers scores sb + 1 .. sb + TMAX
@@ -1231,11 +1237,11 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
               const int mm = (int)mm2[e];
-              const int hmax = clamp_from_m1(hbase + 2 * r + e, tlen);
+              const int hmax = hmaxv[2 * r + e];
               lane_oob |= lane_on && mm > hmax;
               // (h < k, i.e. a negative pattern position, never occurs in a real wavefront; the halo lanes' stale values
               // -- which are extended like any other now that chained sweeps read them back -- may hold anything)
-              m[2 * r + e] = (mm > hmax || mm < max(k0 + 2 * r + e, 0) || !in_hull) ? OFF_NULL : mm;
+              m[2 * r + e] = (mm > hmax || mm < hminv[2 * r + e] || !in_hull) ? OFF_NULL : mm;
             }
           }
           if (DEEP && lane_on) {  // this score's I/D rows (canonical form), whole lane vectors over the step's hull
