@@ -964,6 +964,7 @@ constexpr int TMAX = AWV_TMAX;  // steps per sweep (one burst of row loads)
 // of one window run back to back with those rows (and the I/D queues) in registers: per 15 scores a window
 // then loads 6 + 15 + 10 + 5 + 15 (gap-open-2 sources, always from memory) ... see DESIGN.md section 4.
 constexpr int CHAIN_MAX = AWV_CHAIN_MAX;
+constexpr int TMAX32 = 3;  // steps per sweep with 32-bit rows (a lane vector is four registers: 3 x 3 sources + the I/D queues = 60)
 constexpr int MSTEPS = 16;  // most steps one pass can cover (a lane table entry per step and per source)
 static_assert(TMAX >= 2 && TMAX <= 8 && TMAX * CHAIN_MAX <= MSTEPS - 1, "pass length");
 
@@ -1052,11 +1053,14 @@ template <bool P2, typename OffT, int E1, int E2, bool BASE, bool CHAIN>
 __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh, const Lds<OffT>& lds, const SubCtx& cx, rsrc_t rs,
                                                   int dir, int s0, const MultiPlan& mp, Acc& acc, int* maxak_out, unsigned& ext_iters) {
   constexpr bool DEEP = BASE;  // every step's I/D rows go to memory
-  static_assert(sizeof(OffT) == 2, "multi-step windows: 16-bit rows");
+  constexpr bool W16 = sizeof(OffT) == 2;  // 16-bit rows: packed arithmetic; 32-bit rows: the same recurrences on 32-bit registers
   static_assert(E1 >= 1 && E1 <= 2 && E2 >= 1 && E2 <= 2, "register-resident I/D depth");
   static_assert(!(BASE && CHAIN), "the base case runs single sweeps");
+  static_assert(W16 || !CHAIN, "chained sweeps: 16-bit rows only (a 32-bit sweep's sources alone fill the registers)");
   constexpr int NWAVES = WG / 64;
-  constexpr int VEC = 4, ESZ = 2;
+  constexpr int VEC = 4, ESZ = (int)sizeof(OffT);
+  constexpr int TM = W16 ? TMAX : TMAX32;  // steps per sweep
+  constexpr int NW = W16 ? 2 : 4;          // 32-bit words per lane vector
   constexpr int NS0 = 2 * E1 + (P2 ? 2 * E2 : 0);
   constexpr int NT = P2 ? 3 : 2;
   typedef RawVec<OffT> V;
@@ -1071,7 +1075,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
     return 0;
   }
   const int colLoMin = mp.lo_min - kmin, colHiMax = mp.hi_max - kmin;
-  const unsigned nullw = ((unsigned)(unsigned short)NULL16) * 0x00010001u;
+  const unsigned nullw = W16 ? ((unsigned)(unsigned short)NULL16) * 0x00010001u : (unsigned)OFF_NULL;
   const int halo = mp.halo;                 // unproductive lanes on either side: their columns go invalid one per step
   const int stride = (64 - 2 * halo) * VEC;  // new columns per window
   const bool productive = lane >= halo && lane < 64 - halo;
@@ -1092,10 +1096,25 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
   };
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   auto st = [&](int soff, int voff, const V& v) {
-    u32x2 w2;
-    w2[0] = v.w[0];
-    w2[1] = v.w[1];
-    __builtin_amdgcn_raw_buffer_store_b64(w2, rs, voff, soff, 0);
+    if constexpr (W16) {
+      u32x2 w2;
+      w2[0] = v.w[0];
+      w2[1] = v.w[1];
+      __builtin_amdgcn_raw_buffer_store_b64(w2, rs, voff, soff, 0);
+    } else {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 w4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w4[j] = v.w[j];
+      __builtin_amdgcn_raw_buffer_store_b128(w4, rs, voff, soff, 0);
+    }
+  };
+  // stored form of an I/D vector: canonical halves with 16-bit rows, the values themselves with 32-bit rows
+  auto stored = [&](const V& v) {
+    V o;
+#pragma unroll
+    for (int r = 0; r < NW; ++r) o.w[r] = W16 ? canon(v.w[r]) : v.w[r];
+    return o;
   };
   int nwin = 0;
   for (int cb = (colLoMin & ~(VEC - 1)) - halo * VEC + (NWAVES > 1 ? (int)(threadIdx.x >> 6) * stride : 0); cb + halo * VEC <= colHiMax;
@@ -1110,8 +1129,8 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
     auto lmask = [&](int r, V& v) {  // edge windows: lane vectors outside the hull of a source's step hold nothing (or stale data)
       const int alo = __builtin_amdgcn_readlane(mp.vlo, r), ahi = __builtin_amdgcn_readlane(mp.vhi, r);
       const bool keep = c0 >= alo && c0 <= ahi;
-      v.w[0] = keep ? v.w[0] : nullw;
-      v.w[1] = keep ? v.w[1] : nullw;
+#pragma unroll
+      for (int r = 0; r < NW; ++r) v.w[r] = keep ? v.w[r] : nullw;
     };
     const unsigned long long tm0 = PROF_NOW();
     // ---- the I/D rows the pass begins with
@@ -1135,9 +1154,9 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
       }
     }
     // the last two sweeps' own M rows (canonical stored form), what the next sweeps read 5 / 10 scores back
-    V Mp1[CHAIN ? TMAX : 1], Mp2[CHAIN ? TMAX : 1];
+    V Mp1[CHAIN ? TM : 1], Mp2[CHAIN ? TM : 1];
 #pragma unroll
-    for (int t = 0; t < (CHAIN ? TMAX : 1); ++t) { Mp1[t] = V{}; Mp2[t] = V{}; }
+    for (int t = 0; t < (CHAIN ? TM : 1); ++t) { Mp1[t] = V{}; Mp2[t] = V{}; }
     // per cell, the largest / smallest offset inside the matrix on its diagonal (the same for every step of the pass)
     int hmaxv[VEC], hminv[VEC];
 #pragma unroll
@@ -1147,19 +1166,19 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
     }
 #pragma nounroll
     for (int h = 0; h < nh; ++h) {
-      const int sb = s0 + h * TMAX;   // this sweep covers scores sb + 1 .. sb + TMAX
-      const int tb = h * TMAX;        // its first step index within the pass
-      const int tn = min(TMAX, Tn - tb);
+      const int sb = s0 + h * TM;   // this sweep covers scores sb + 1 .. sb + TM
+      const int tb = h * TM;        // its first step index within the pass
+      const int tn = min(TM, Tn - tb);
       const bool own0 = CHAIN && h >= 1, own1 = CHAIN && h >= 2;  // (uniform) M sources 0 / 1 come from registers
       // ---- all row loads of the sweep, back to back
-      V tap[TMAX][NT];
+      V tap[TM][NT];
 #pragma unroll
-      for (int t = 0; t < TMAX; ++t)
+      for (int t = 0; t < TM; ++t)
 #pragma unroll
         for (int w = 0; w < NT; ++w) tap[t][w] = V{};
       if (load_on) {
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
+        for (int t = 0; t < TM; ++t) {
           if (t < tn) {
             if (!own0) tap[t][0] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.x));
             if (!own1) tap[t][1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o1 - pn.e1));
@@ -1177,7 +1196,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           }
         }
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
+        for (int t = 0; t < TM; ++t) {
           if (t < tn) {
             if (!own0) lmask(NS0 + tb + t, tap[t][0]);
             if (!own1) lmask(NS0 + 16 + tb + t, tap[t][1]);
@@ -1188,9 +1207,9 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
       PROF_DRAIN();
       PROF_ADD_L(STAT_T_CR_LOAD, tm0);
       // ---- the steps
-      V Mnew[CHAIN ? TMAX : 1];
+      V Mnew[CHAIN ? TM : 1];
 #pragma unroll
-      for (int t = 0; t < TMAX; ++t) {
+      for (int t = 0; t < TM; ++t) {
         if (t < tn) {
           const unsigned long long tm1 = PROF_NOW();
           const int lo_t = __builtin_amdgcn_readlane(mp.vslo, tb + t), hi_t = __builtin_amdgcn_readlane(mp.vshi, tb + t);
@@ -1203,66 +1222,98 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             if (own0) cMx = Mp1[t];
             if (own1) cO1 = Mp2[t];
           }
-          // max first, neighbour shift after: max(O[k-1], I[k-1]) = (max(O, I))[k-1] -- one shift per gap kind instead of two
-          auto pkmax = [&](const V& a, const V& b) {
-            V o;
-            o.w[0] = asu(__builtin_elementwise_max(as2(a.w[0]), as2(b.w[0])));
-            o.w[1] = asu(__builtin_elementwise_max(as2(a.w[1]), as2(b.w[1])));
-            return o;
-          };
-          const V sI1 = shift_from_left(pkmax(cO1, qI1[0])), sD1 = shift_from_right(pkmax(cO1, qD1[0]));
-          V sI2{}, sD2{};
-          if (P2) {
-            sI2 = shift_from_left(pkmax(tap[t][NT - 1], qI2[0]));
-            sD2 = shift_from_right(pkmax(tap[t][NT - 1], qD2[0]));
-          }
-          V nI1, nD1, nI2{}, nD2{};
+          V nI1{}, nD1{}, nI2{}, nD2{};
           int32_t m[VEC];
-#pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            const s2 ins1 = as2(sI1.w[r]) + one;
-            const s2 del1 = as2(sD1.w[r]);
-            s2 ins = ins1, del = del1;
-            nI1.w[r] = asu(ins1);
-            nD1.w[r] = asu(del1);
+          if constexpr (W16) {
+            // max first, neighbour shift after: max(O[k-1], I[k-1]) = (max(O, I))[k-1] -- one shift per gap kind instead of two
+            auto pkmax = [&](const V& a, const V& b) {
+              V o;
+              o.w[0] = asu(__builtin_elementwise_max(as2(a.w[0]), as2(b.w[0])));
+              o.w[1] = asu(__builtin_elementwise_max(as2(a.w[1]), as2(b.w[1])));
+              return o;
+            };
+            const V sI1 = shift_from_left(pkmax(cO1, qI1[0])), sD1 = shift_from_right(pkmax(cO1, qD1[0]));
+            V sI2{}, sD2{};
             if (P2) {
-              const s2 ins2 = as2(sI2.w[r]) + one;
-              const s2 del2 = as2(sD2.w[r]);
-              ins = __builtin_elementwise_max(ins, ins2);
-              del = __builtin_elementwise_max(del, del2);
-              nI2.w[r] = asu(ins2);
-              nD2.w[r] = asu(del2);
+              sI2 = shift_from_left(pkmax(tap[t][NT - 1], qI2[0]));
+              sD2 = shift_from_right(pkmax(tap[t][NT - 1], qD2[0]));
             }
-            const s2 mm2 = __builtin_elementwise_max(del, __builtin_elementwise_max(as2(cMx.w[r]) + one, ins));
+  #pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const s2 ins1 = as2(sI1.w[r]) + one;
+              const s2 del1 = as2(sD1.w[r]);
+              s2 ins = ins1, del = del1;
+              nI1.w[r] = asu(ins1);
+              nD1.w[r] = asu(del1);
+              if (P2) {
+                const s2 ins2 = as2(sI2.w[r]) + one;
+                const s2 del2 = as2(sD2.w[r]);
+                ins = __builtin_elementwise_max(ins, ins2);
+                del = __builtin_elementwise_max(del, del2);
+                nI2.w[r] = asu(ins2);
+                nD2.w[r] = asu(del2);
+              }
+              const s2 mm2 = __builtin_elementwise_max(del, __builtin_elementwise_max(as2(cMx.w[r]) + one, ins));
+  #pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const int mm = (int)mm2[e];
+                const int hmax = hmaxv[2 * r + e];
+                lane_oob |= lane_on && mm > hmax;
+                // (h < k, i.e. a negative pattern position, never occurs in a real wavefront; the halo lanes' stale values
+                // -- which are extended like any other now that chained sweeps read them back -- may hold anything)
+                m[2 * r + e] = (mm > hmax || mm < hminv[2 * r + e] || !in_hull) ? OFF_NULL : mm;
+              }
+            }
+          } else {
+            const V rO1l = shift_from_left(cO1), rO1r = shift_from_right(cO1);
+            const V rI1 = shift_from_left(qI1[0]), rD1 = shift_from_right(qD1[0]);
+            V rO2l{}, rO2r{}, rI2{}, rD2{};
+            if (P2) {
+              rO2l = shift_from_left(tap[t][NT - 1]);
+              rO2r = shift_from_right(tap[t][NT - 1]);
+              rI2 = shift_from_left(qI2[0]);
+              rD2 = shift_from_right(qD2[0]);
+            }
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              const int mm = (int)mm2[e];
-              const int hmax = hmaxv[2 * r + e];
+            for (int j = 0; j < VEC; ++j) {
+              const int32_t ins1 = max((int32_t)rO1l.w[j], (int32_t)rI1.w[j]) + 1;
+              const int32_t del1 = max((int32_t)rO1r.w[j], (int32_t)rD1.w[j]);
+              int32_t ins = ins1, del = del1;
+              nI1.w[j] = (unsigned)ins1;
+              nD1.w[j] = (unsigned)del1;
+              if (P2) {
+                const int32_t ins2 = max((int32_t)rO2l.w[j], (int32_t)rI2.w[j]) + 1;
+                const int32_t del2 = max((int32_t)rO2r.w[j], (int32_t)rD2.w[j]);
+                ins = max(ins, ins2);
+                del = max(del, del2);
+                nI2.w[j] = (unsigned)ins2;
+                nD2.w[j] = (unsigned)del2;
+              }
+              const int32_t mm = max(del, max((int32_t)cMx.w[j] + 1, ins));
+              const int hmax = hmaxv[j];
               lane_oob |= lane_on && mm > hmax;
-              // (h < k, i.e. a negative pattern position, never occurs in a real wavefront; the halo lanes' stale values
-              // -- which are extended like any other now that chained sweeps read them back -- may hold anything)
-              m[2 * r + e] = (mm > hmax || mm < hminv[2 * r + e] || !in_hull) ? OFF_NULL : mm;
+              m[j] = (mm > hmax || mm < hminv[j] || !in_hull) ? OFF_NULL : mm;
             }
           }
           if (DEEP && lane_on) {  // this score's I/D rows (canonical form), whole lane vectors over the step's hull
-            V a, b;
-            a.w[0] = canon(nI1.w[0]); a.w[1] = canon(nI1.w[1]);
-            b.w[0] = canon(nD1.w[0]); b.w[1] = canon(nD1.w[1]);
-            st(row_off<BASE, OffT>(kp, dir, C_I1, sb + 1 + t), voff, a);
-            st(row_off<BASE, OffT>(kp, dir, C_D1, sb + 1 + t), voff, b);
+            st(row_off<BASE, OffT>(kp, dir, C_I1, sb + 1 + t), voff, stored(nI1));
+            st(row_off<BASE, OffT>(kp, dir, C_D1, sb + 1 + t), voff, stored(nD1));
             if (P2) {
-              a.w[0] = canon(nI2.w[0]); a.w[1] = canon(nI2.w[1]);
-              b.w[0] = canon(nD2.w[0]); b.w[1] = canon(nD2.w[1]);
-              st(row_off<BASE, OffT>(kp, dir, C_I2, sb + 1 + t), voff, a);
-              st(row_off<BASE, OffT>(kp, dir, C_D2, sb + 1 + t), voff, b);
+              st(row_off<BASE, OffT>(kp, dir, C_I2, sb + 1 + t), voff, stored(nI2));
+              st(row_off<BASE, OffT>(kp, dir, C_D2, sb + 1 + t), voff, stored(nD2));
             }
           }
           if (BASE && mp.end_comp != C_M) {  // end cell in an indel component: has its offset reached the text end?
             const V& ev = mp.end_comp == C_I1 ? nI1 : mp.end_comp == C_D1 ? nD1 : mp.end_comp == C_I2 ? nI2 : nD2;
             const int je = mp.end_col - c0;  // element of this lane's vector, if it holds the end column
             const bool mine = lane_on && je >= 0 && je < VEC;
-            const unsigned w = (je & 2) ? ev.w[1] : ev.w[0];
-            const int val = (je & 1) ? ((int)w >> 16) : (((int)w << 16) >> 16);
+            int val;
+            if constexpr (W16) {
+              const unsigned w = (je & 2) ? ev.w[1] : ev.w[0];
+              val = (je & 1) ? ((int)w >> 16) : (((int)w << 16) >> 16);
+            } else {
+              val = (int)(je == 0 ? ev.w[0] : je == 1 ? ev.w[1] : je == 2 ? ev.w[2] : ev.w[3]);
+            }
             if (__any(mine && val >= tlen)) reach_mask |= 1u << (tb + t);
           }
           PROF_DRAIN();
@@ -1275,8 +1326,16 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           {  // canonical stored form of the M cells: what goes to memory and what the next sweeps read back
             V mv;
             int c[VEC];
-            mv.w[0] = pack_canon16(m[0], m[1], tlen + 1, c[0], c[1]);
-            mv.w[1] = pack_canon16(m[2], m[3], tlen + 1, c[2], c[3]);
+            if constexpr (W16) {
+              mv.w[0] = pack_canon16(m[0], m[1], tlen + 1, c[0], c[1]);
+              mv.w[1] = pack_canon16(m[2], m[3], tlen + 1, c[2], c[3]);
+            } else {
+#pragma unroll
+              for (int j = 0; j < VEC; ++j) {
+                mv.w[j] = (unsigned)m[j];
+                c[j] = max(m[j], -(1 << 28));  // (a clamp from below for the antidiagonal maximum: 2 c - k stays far below 0 for a NULL, without overflow)
+              }
+            }
             if (!BASE) {
               // the pass's max antidiagonal, reduced once after the last window.  From the clamped values: a NULL is
               // -16384 there, so 2 c - k stays far below any real antidiagonal without a test per cell; cells outside
@@ -1310,7 +1369,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
       }
       if (CHAIN) {
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) { Mp2[t] = Mp1[t]; Mp1[t] = Mnew[t]; }
+        for (int t = 0; t < TM; ++t) { Mp2[t] = Mp1[t]; Mp1[t] = Mnew[t]; }
       }
     }
     // ---- the pass's last e1 / e2 I/D rows (canonical form, whole lane vectors over their step's hull)
@@ -1322,11 +1381,8 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
         const int lo_j = __builtin_amdgcn_readlane(mp.vslo, tj), hi_j = __builtin_amdgcn_readlane(mp.vshi, tj);
         const bool on = productive && c0 + VEC > lo_j - kmin && c0 <= hi_j - kmin;
         if (on) {
-          V a, b;
-          a.w[0] = canon(qI1[j].w[0]); a.w[1] = canon(qI1[j].w[1]);
-          b.w[0] = canon(qD1[j].w[0]); b.w[1] = canon(qD1[j].w[1]);
-          st(row_off<BASE, OffT>(kp, dir, C_I1, s0 + 1 + tj), voff, a);
-          st(row_off<BASE, OffT>(kp, dir, C_D1, s0 + 1 + tj), voff, b);
+          st(row_off<BASE, OffT>(kp, dir, C_I1, s0 + 1 + tj), voff, stored(qI1[j]));
+          st(row_off<BASE, OffT>(kp, dir, C_D1, s0 + 1 + tj), voff, stored(qD1[j]));
         }
       }
       if (P2) {
@@ -1336,11 +1392,8 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           const int lo_j = __builtin_amdgcn_readlane(mp.vslo, tj), hi_j = __builtin_amdgcn_readlane(mp.vshi, tj);
           const bool on = productive && c0 + VEC > lo_j - kmin && c0 <= hi_j - kmin;
           if (on) {
-            V a, b;
-            a.w[0] = canon(qI2[j].w[0]); a.w[1] = canon(qI2[j].w[1]);
-            b.w[0] = canon(qD2[j].w[0]); b.w[1] = canon(qD2[j].w[1]);
-            st(row_off<BASE, OffT>(kp, dir, C_I2, s0 + 1 + tj), voff, a);
-            st(row_off<BASE, OffT>(kp, dir, C_D2, s0 + 1 + tj), voff, b);
+            st(row_off<BASE, OffT>(kp, dir, C_I2, s0 + 1 + tj), voff, stored(qI2[j]));
+            st(row_off<BASE, OffT>(kp, dir, C_D2, s0 + 1 + tj), voff, stored(qD2[j]));
           }
         }
       }
@@ -1738,7 +1791,7 @@ __device__ __forceinline__ int base_align(const KParams& kp, Shared& sh, const L
     acc_reset(sh.acc[1][0]);
     acc_reset(sh.acc[2][0]);
   }
-  constexpr bool MULTI_BUILD = sizeof(OffT) == 2 && !DIRSPLIT;
+  constexpr bool MULTI_BUILD = !DIRSPLIT;
   const unsigned sh_addr = (unsigned)(uintptr_t)&sh, dyn_addr = (unsigned)(uintptr_t)lds.ring_meta;  // LDS addresses
   if (MULTI_BUILD && tid == 0) {  // what base_phase reads back (uniform; the barrier below publishes it)
     PassCtx& pc = sh.pctx;
@@ -2167,7 +2220,7 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
     if (cx.wcols > kp.wcap) return ST_CAPACITY;
   }
   const unsigned sh_addr = (unsigned)(uintptr_t)&sh, dyn_addr = (unsigned)(uintptr_t)lds.ring_meta;  // LDS addresses (low half of the flat ones)
-  if (sizeof(OffT) == 2 && !DIRSPLIT && tid == 0) {  // what multi_pass reads back (uniform; the barrier below publishes it)
+  if (!DIRSPLIT && tid == 0) {  // what multi_phase reads back (uniform; the barrier below publishes it)
     PassCtx& pc = sh.pctx;
     pc.ring_mem = (unsigned long long)(uintptr_t)ring_mem;
     pc.ring_bytes = (unsigned long long)kp.ring_slot_stride;
@@ -2237,7 +2290,7 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
   bool dirty[2] = {false, false};  // per direction: some row was trimmed, later steps mask element by element
   // Multi-step passes (compute_rows_multi) while the searches are far apart; step by step -- every I/D
   // row kept, as the overlap search needs them -- from a safe margin before they can meet.
-  constexpr bool MULTI_BUILD = sizeof(OffT) == 2 && !DIRSPLIT;
+  constexpr bool MULTI_BUILD = !DIRSPLIT;
   const int multi_T = (MULTI_BUILD && !force_single && plen + tlen > 1024) ? kp.multi_T : 0;  // 0: step by step throughout
   bool deep_on = multi_T == 0;     // every step stores its I/D rows
   int deep_since[2] = {deep_on ? 0 : INT_MAX, deep_on ? 0 : INT_MAX};  // first score from which all I/D rows are in HBM
@@ -2266,7 +2319,7 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
         // ---- the far-apart phase: all multi-step passes of this search in one call (multi_phase)
         if constexpr (MULTI_BUILD) {
           // (chained sweeps only where the scores allow them: 2-piece with x = TMAX and o1 + e1 = 2 TMAX, the default set)
-          if (P2) multi_phase<P2, OffT, 2, 1, P2>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
+          if (P2) multi_phase<P2, OffT, 2, 1, P2 && sizeof(OffT) == 2>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
           else if (pn.e1 == 1) multi_phase<P2, OffT, 1, 1, false>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
           else multi_phase<P2, OffT, 2, 1, false>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
         }
@@ -2372,7 +2425,7 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
     lstats[STAT_BREAKPOINTS] += 1;
   }
   atomicAdd(&lstats[STAT_EXTEND], (unsigned long long)ext_iters);
-  if (sizeof(OffT) == 2 && !DIRSPLIT && tid == 0) lstats[STAT_EXTEND] += sh.ext_multi;
+  if (!DIRSPLIT && tid == 0) lstats[STAT_EXTEND] += sh.ext_multi;
   __syncthreads();  // LDS metadata is rewritten by the next sub-problem
   if (rc == BP_OK && bp.score == INT_MAX) rc = ST_INTERNAL;
   return rc;
