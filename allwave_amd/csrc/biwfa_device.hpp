@@ -1501,7 +1501,10 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
     int nh = 0;
     for (int c = chain_cap; c >= 1; --c) {
       const int T = c > 1 ? TMAX * c : Tn;
-      if (arun0 + arun1 < max_antidiagonal - (MARGIN_BASE + MARGIN_MUL4 * (kp.pen.scope + T) * max(grow, 8) / 4)) { nh = c; break; }
+      // (32-bit rows = long sequences with long exact runs: the searches advance in larger bursts, 2.0 x instead of 1.5 x -- config 4:
+      // 9.91 s and 4.9 k restarted searches against 10.31 s and 26 k)
+      const int mul4 = sizeof(OffT) == 2 ? MARGIN_MUL4 : MARGIN_MUL4 + 2;
+      if (arun0 + arun1 < max_antidiagonal - (MARGIN_BASE + mul4 * (kp.pen.scope + T) * max(grow, 8) / 4)) { nh = c; break; }
     }
     if (nh == 0) { why = MP_MARGIN; break; }
     const int T = nh > 1 ? TMAX * nh : Tn;
