@@ -135,7 +135,7 @@ struct Acc { int hull_lo[NCOMP]; int hull_hi[NCOMP]; int maxak; int oob; int rea
 struct Task { int pb, pe, tb, te, cb, ce, score_remaining, known; };  // known: the sub-problem's optimal score (INT_MAX at the top)
 struct Breakpoint { int score, sf, sr, kf, kr, off_f, off_r, comp; };
 
-struct RowMeta16 { int16_t lo, hi; };  // |k| < 32760 whenever 16-bit rows are in use; empty = {1, 0}
+struct alignas(4) RowMeta16 { int16_t lo, hi; };  // (one 32-bit LDS access, also where the compiler cannot see the base's alignment)  // |k| < 32760 whenever 16-bit rows are in use; empty = {1, 0}
 template <typename OffT> struct MetaTraits;
 template <> struct MetaTraits<int16_t> { typedef RowMeta16 Stored; };
 template <> struct MetaTraits<int32_t> { typedef RowMeta Stored; };
@@ -178,6 +178,9 @@ struct PassCtx {
   // base case (base_phase): history arena instead of the ring, the metadata log, capacities, the end cell
   unsigned long long meta_log;
   int wb_cap, sb_cap, end_comp;
+  // the breakpoint search as a function (find_breakpoint_fn): launch constants and the staged-sequence bookkeeping of the sub-problem
+  unsigned long long Pw, Tw;
+  int multi_T, lds_seq_bytes, pb_abs, tb_abs;
 };
 struct PhaseResult { int why, sc, fmax, rmax, npass; unsigned long long cells; };
 struct Shared {
@@ -185,6 +188,7 @@ struct Shared {
   int chain_maxak[2][16];  // multi_phase: per direction and step of the running pass, the row's max antidiagonal
   PassCtx pctx;
   PhaseResult pres;
+  Breakpoint bp_out;  // find_breakpoint_fn's result
   unsigned long long ext_multi;  // extend probes counted by multi-step passes
   unsigned int win_single, win_multi, win_base, win_base_multi;  // windows processed (diagnostics)
   int ext0[2];
@@ -1440,8 +1444,8 @@ constexpr int MP_MARGIN = 0, MP_DISCARD = 1, MP_MET = 2, MP_ERROR = 3;
 constexpr int MARGIN_BASE = AWV_MARGIN_BASE, MARGIN_MUL4 = AWV_MARGIN_MUL4;
 template <bool P2, typename OffT, int E1, int E2, bool CHAIN>
 __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned dyn_addr, int s0_v, int fmax_v, int rmax_v, int Tn_v, int pass_v) {
-  Shared& sh = *(Shared*)(lds_shared_ptr)(uintptr_t)sh_addr;
-  unsigned char* dyn_smem = (unsigned char*)(lds_bytes_ptr)(uintptr_t)dyn_addr;
+  Shared& sh = *(Shared*)__builtin_assume_aligned((Shared*)(lds_shared_ptr)(uintptr_t)uni((int)sh_addr), 8);
+  unsigned char* dyn_smem = (unsigned char*)__builtin_assume_aligned((unsigned char*)(lds_bytes_ptr)(uintptr_t)uni((int)dyn_addr), 16);
   const int Tn = uni(Tn_v);
   int sc = uni(s0_v);  // both directions stand at the same score when the phase begins and after every pass
   int fmax = uni(fmax_v), rmax = uni(rmax_v), pass = uni(pass_v);
@@ -1576,8 +1580,8 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
 // pres.sc) or the history's score capacity comes near (MP_MARGIN: likewise).
 template <bool P2, typename OffT, int E1, int E2>
 __device__ __attribute__((noinline)) void base_phase(unsigned sh_addr, unsigned dyn_addr, int s0_v, int Tn_v, int pass_v) {
-  Shared& sh = *(Shared*)(lds_shared_ptr)(uintptr_t)sh_addr;
-  unsigned char* dyn_smem = (unsigned char*)(lds_bytes_ptr)(uintptr_t)dyn_addr;
+  Shared& sh = *(Shared*)__builtin_assume_aligned((Shared*)(lds_shared_ptr)(uintptr_t)uni((int)sh_addr), 8);
+  unsigned char* dyn_smem = (unsigned char*)__builtin_assume_aligned((unsigned char*)(lds_bytes_ptr)(uintptr_t)uni((int)dyn_addr), 16);
   const int Tn = uni(Tn_v);
   int sc = uni(s0_v), pass = uni(pass_v);
   const PassCtx& pc = sh.pctx;
@@ -1617,7 +1621,7 @@ __device__ __attribute__((noinline)) void base_phase(unsigned sh_addr, unsigned 
   lds.bi_oob = lds.bi_A + 2 * kp.ring;
   lds.firstk = lds.bi_oob + 2 * kp.ring;
   lds.seq = reinterpret_cast<uint32_t*>(dyn_smem + kp.lds_meta_bytes);
-  lds.meta_log = (RowMeta*)(uintptr_t)uni64(pc.meta_log);
+  lds.meta_log = (RowMeta*)(__attribute__((address_space(1))) RowMeta*)(uintptr_t)uni64(pc.meta_log);
   const rsrc_t rs = make_rsrc((void*)(uintptr_t)uni64(pc.ring_mem), (size_t)uni64(pc.ring_bytes));
   const int end_comp = uni(pc.end_comp);
   const int end_col = (cx.tlen - cx.plen) - cx.kmin[0];
@@ -1672,29 +1676,57 @@ __device__ __attribute__((noinline)) void base_phase(unsigned sh_addr, unsigned 
 template <bool P2, bool BASE, typename OffT>
 __device__ __forceinline__ void trim_pass(const KParams& kp, const SubCtx& cx, void* mem, int dir, int score,
                                           int lo, int hi, Acc& acc) {
+  // The trimmed range of a component = [first in-bounds cell, last in-bounds cell] of the row just written.
+  // Out-of-bounds cells sit at the row's ends (where the wavefront runs off the matrix), so the row is
+  // searched from both ends inwards, 64 columns at a time, and each end stops at its first hit: a few
+  // chunks per step instead of the whole row -- which for the rows of a forced gap (tens of thousands of
+  // columns, trimmed at every score) used to cost more than computing them.  Every wave searches its own
+  // chunks (chunk i belongs to wave i mod nwaves); the minimum / maximum over the waves is the row's.
+  constexpr int NW = WG / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kmin = cx.kmin[dir];
   const int plen = cx.plen, tlen = cx.tlen;
   const int colLo = lo - kmin, colHi = hi - kmin;
-  int wlo[NCOMP], whi[NCOMP];
+  const int first = colLo & ~63;
+  const int n = (colHi - first) / 64 + 1;  // chunks of the row
+  int wlo[NCOMP], whi[NCOMP], ilo[NCOMP];
 #pragma unroll
-  for (int c = 0; c < NCOMP; ++c) { wlo[c] = INT_MAX; whi[c] = INT_MIN; }
-  for (int cb = (colLo & ~63) + 64 * wave; cb <= colHi; cb += WG) {
+  for (int c = 0; c < NCOMP; ++c) { wlo[c] = INT_MAX; whi[c] = INT_MIN; ilo[c] = -1; }
+  auto chunk_mask = [&](int c, int i) -> uint64_t {
+    const int cb = first + 64 * i;
     const int col = cb + lane;
     const int k = col + kmin;
-    const bool act = col >= colLo && col <= colHi;
+    bool inb = false;
+    if (col >= colLo && col <= colHi) {
+      const int32_t v = off_load1<OffT>(row_ptr<BASE, OffT>(kp, mem, dir, c, score) + col);
+      inb = (uint32_t)v <= (uint32_t)tlen && (uint32_t)(v - k) <= (uint32_t)plen;
+    }
+    return __ballot(inb);
+  };
+  const unsigned all = P2 ? 0x1Fu : ((1u << C_M) | (1u << C_I1) | (1u << C_D1));
+  unsigned need = all;
+  for (int i = wave; i < n && need; i += NW) {  // from the low end
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c) {
-      if (!P2 && (c == C_I2 || c == C_D2)) continue;
-      bool inb = false;
-      if (act) {
-        const int32_t v = off_load1<OffT>(row_ptr<BASE, OffT>(kp, mem, dir, c, score) + col);
-        inb = (uint32_t)v <= (uint32_t)tlen && (uint32_t)(v - k) <= (uint32_t)plen;
-      }
-      const uint64_t mask = __ballot(inb);
+      if (!((need >> c) & 1u)) continue;
+      const uint64_t mask = chunk_mask(c, i);
       if (mask) {
-        wlo[c] = min(wlo[c], cb + (int)__builtin_ctzll(mask));
-        whi[c] = max(whi[c], cb + 63 - (int)__builtin_clzll(mask));
+        wlo[c] = first + 64 * i + (int)__builtin_ctzll(mask);
+        ilo[c] = i;
+        need &= ~(1u << c);
+      }
+    }
+  }
+  unsigned needh = all & ~need;  // (a component without a hit among this wave's chunks has none to find from the other end either)
+  const int ilast = n - 1 - (((n - 1 - wave) % NW + NW) % NW);  // this wave's last chunk (< wave: it has none)
+  for (int i = ilast; i >= 0 && needh; i -= NW) {  // from the high end; ends at the chunk of the low-end hit at the latest
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      if (!((needh >> c) & 1u)) continue;
+      const uint64_t mask = chunk_mask(c, i);
+      if (mask) {
+        whi[c] = first + 64 * i + 63 - (int)__builtin_clzll(mask);
+        needh &= ~(1u << c);
       }
     }
   }
@@ -1707,6 +1739,29 @@ __device__ __forceinline__ void trim_pass(const KParams& kp, const SubCtx& cx, v
       }
     }
   }
+}
+
+// trim_pass as a function of its own (never inlined into the step-by-step loop, whose register allocation is
+// full: inlined, the two-ended search cost config 2 ten per cent through spills in that loop).  Geometry
+// comes from Shared::pctx (written by find_breakpoint / base_align for the running sub-problem).
+template <bool P2, bool BASE, typename OffT>
+__device__ __attribute__((noinline)) void trim_pass_fn(unsigned sh_addr, int dir_v, int score_v, int lo_v, int hi_v, int aslot_v) {
+  Shared& sh = *(Shared*)__builtin_assume_aligned((Shared*)(__attribute__((address_space(3))) Shared*)(uintptr_t)uni((int)sh_addr), 8);
+  const int dir = uni(dir_v), score = uni(score_v), lo = uni(lo_v), hi = uni(hi_v), aslot = uni(aslot_v);
+  const PassCtx& pc = sh.pctx;
+  KParams kp{};
+  kp.ring = uni(pc.ring);
+  kp.wcap = uni(pc.wcap);
+  kp.wb_cap = uni(pc.wb_cap);
+  SubCtx cx;
+  cx.plen = uni(pc.plen);
+  cx.tlen = uni(pc.tlen);
+  cx.kmin[0] = uni(pc.kmin[0]);
+  cx.kmin[1] = uni(pc.kmin[1]);
+  void* mem = (void*)(__attribute__((address_space(1))) char*)(uintptr_t)(((unsigned long long)(unsigned)uni((int)(pc.ring_mem >> 32)) << 32) | (unsigned)uni((int)pc.ring_mem));
+  Acc& acc = dir ? sh.acc[aslot][1] : sh.acc[aslot][0];
+  if (dir) trim_pass<P2, BASE, OffT>(kp, cx, mem, 1, score, lo, hi, acc);
+  else trim_pass<P2, BASE, OffT>(kp, cx, mem, 0, score, lo, hi, acc);
 }
 
 // after the barrier: every thread writes the same values (benign same-value stores).  The predicted
@@ -1796,7 +1851,7 @@ __device__ __forceinline__ int base_align(const KParams& kp, Shared& sh, const L
   }
   constexpr bool MULTI_BUILD = !DIRSPLIT;
   const unsigned sh_addr = (unsigned)(uintptr_t)&sh, dyn_addr = (unsigned)(uintptr_t)lds.ring_meta;  // LDS addresses
-  if (MULTI_BUILD && tid == 0) {  // what base_phase reads back (uniform; the barrier below publishes it)
+  if (tid == 0) {  // what base_phase / trim_pass_fn read back (uniform; the barrier below publishes it)
     PassCtx& pc = sh.pctx;
     pc.ring_mem = (unsigned long long)(uintptr_t)hist_mem;
     pc.ring_bytes = (unsigned long long)kp.hist_slot_stride;
@@ -1858,7 +1913,7 @@ __device__ __forceinline__ int base_align(const KParams& kp, Shared& sh, const L
     const bool trim = uni(acc.oob) != 0;
     dirty = dirty || trim;
     if (trim) {
-      trim_pass<P2, true, OffT>(kp, cx, hist_mem, 0, score, pl.lo, pl.hi, acc);
+      trim_pass_fn<P2, true, OffT>(sh_addr, 0, score, pl.lo, pl.hi, pass % 3);
       __syncthreads();
     }
     finalize_row<true, OffT>(kp, lds, cx, 0, score, acc, trim);
@@ -2223,7 +2278,7 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
     if (cx.wcols > kp.wcap) return ST_CAPACITY;
   }
   const unsigned sh_addr = (unsigned)(uintptr_t)&sh, dyn_addr = (unsigned)(uintptr_t)lds.ring_meta;  // LDS addresses (low half of the flat ones)
-  if (!DIRSPLIT && tid == 0) {  // what multi_phase reads back (uniform; the barrier below publishes it)
+  if (tid == 0) {  // what multi_phase / trim_pass_fn read back (uniform; the barrier below publishes it)
     PassCtx& pc = sh.pctx;
     pc.ring_mem = (unsigned long long)(uintptr_t)ring_mem;
     pc.ring_bytes = (unsigned long long)kp.ring_slot_stride;
@@ -2374,8 +2429,8 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
             if (trim0) { const RowMeta mm = get_meta(kp, lds, 0, C_M, sc[0] + 1); plo[0] = mm.lo; phi[0] = mm.hi; }
             if (trim1) { const RowMeta mm = get_meta(kp, lds, 1, C_M, sc[1] + 1); plo[1] = mm.lo; phi[1] = mm.hi; }
           }
-          if (trim0) trim_pass<P2, false, OffT>(kp, cx, ring_mem, 0, sc[0] + 1, plo[0], phi[0], a[0]);
-          if (trim1) trim_pass<P2, false, OffT>(kp, cx, ring_mem, 1, sc[1] + 1, plo[1], phi[1], a[1]);
+          if (trim0) trim_pass_fn<P2, false, OffT>(sh_addr, 0, sc[0] + 1, plo[0], phi[0], pass % 3);
+          if (trim1) trim_pass_fn<P2, false, OffT>(sh_addr, 1, sc[1] + 1, plo[1], phi[1], pass % 3);
           __syncthreads();
         }
         if (need[0]) { finalize_row<false, OffT>(kp, lds, cx, 0, sc[0] + 1, a[0], trim0); comp[0] = sc[0] + 1; }
@@ -2431,6 +2486,72 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
   if (!DIRSPLIT && tid == 0) lstats[STAT_EXTEND] += sh.ext_multi;
   __syncthreads();  // LDS metadata is rewritten by the next sub-problem
   if (rc == BP_OK && bp.score == INT_MAX) rc = ST_INTERNAL;
+  return rc;
+}
+
+// The breakpoint search as a function of its own (never inlined): the DFS loop, the base case and the CIGAR
+// emission keep their state out of its register file, and edits on either side stop perturbing the
+// other's allocation (the step-by-step loop inside is full: an inlined change elsewhere in the kernel
+// once cost config 2 ten per cent through spills there).  Inputs come from Shared::pctx, filled by the
+// kernel for the running sub-problem; the breakpoint goes back through Shared::bp_out.
+template <bool P2, typename OffT>
+__device__ __attribute__((noinline)) int find_breakpoint_fn(unsigned sh_addr, unsigned dyn_addr, unsigned lstats_addr, int cb_v, int ce_v,
+                                                            int score_remaining_v, int known_v, int force_single_v) {
+  Shared& sh = *(Shared*)__builtin_assume_aligned((Shared*)(__attribute__((address_space(3))) Shared*)(uintptr_t)uni((int)sh_addr), 8);
+  unsigned char* dyn_smem = (unsigned char*)__builtin_assume_aligned((unsigned char*)(__attribute__((address_space(3))) unsigned char*)(uintptr_t)uni((int)dyn_addr), 16);
+  unsigned long long* lstats = (unsigned long long*)__builtin_assume_aligned((unsigned long long*)(__attribute__((address_space(3))) unsigned long long*)(uintptr_t)uni((int)lstats_addr), 8);
+  const int cb = uni(cb_v), ce = uni(ce_v), score_remaining = uni(score_remaining_v), known = uni(known_v);
+  const bool force_single = uni(force_single_v) != 0;
+  const PassCtx& pc = sh.pctx;
+  auto uni64 = [](unsigned long long v) { return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)v); };
+  KParams kp{};
+  kp.ring = uni(pc.ring);
+  kp.wcap = uni(pc.wcap);
+  kp.pen.x = uni(pc.x);
+  kp.pen.o1 = uni(pc.o1);
+  kp.pen.e1 = uni(pc.e1);
+  kp.pen.o2 = uni(pc.o2);
+  kp.pen.e2 = uni(pc.e2);
+  kp.pen.two_piece = P2 ? 1 : 0;
+  kp.pen.scope = max(kp.pen.x, max(kp.pen.o1 + kp.pen.e1, P2 ? kp.pen.o2 + kp.pen.e2 : 0)) + 1;
+  kp.lds_meta_bytes = uni(pc.lds_meta_bytes);
+  kp.lds_seq_bytes = uni(pc.lds_seq_bytes);
+  kp.chain_max = uni(pc.chain_max);
+  kp.multi_T = uni(pc.multi_T);
+  kp.ring_slot_stride = (size_t)uni64(pc.ring_bytes);
+  SubCtx cx;
+  cx.plen = uni(pc.plen);
+  cx.tlen = uni(pc.tlen);
+  cx.kmin[0] = cx.kmin[1] = 0;
+  cx.wcols = 0;
+  cx.seq_mode = uni(pc.seq_mode);
+  cx.p_w0 = uni(pc.p_w0);
+  cx.t_w0 = uni(pc.t_w0);
+  cx.p_bit = uni(pc.p_bit);
+  cx.t_bit = uni(pc.t_bit);
+  cx.P[0] = (gseq_t)(uintptr_t)uni64(pc.P[0]);
+  cx.P[1] = (gseq_t)(uintptr_t)uni64(pc.P[1]);
+  cx.T[0] = (gseq_t)(uintptr_t)uni64(pc.T[0]);
+  cx.T[1] = (gseq_t)(uintptr_t)uni64(pc.T[1]);
+  cx.Pw = (gwords_t)(uintptr_t)uni64(pc.Pw);
+  cx.Tw = (gwords_t)(uintptr_t)uni64(pc.Tw);
+  cx.pb_abs = uni(pc.pb_abs);
+  cx.tb_abs = uni(pc.tb_abs);
+  Lds<OffT> lds;
+  typedef typename MetaTraits<OffT>::Stored MetaStored;
+  lds.ring_meta = reinterpret_cast<MetaStored*>(dyn_smem);
+  lds.bi_A = reinterpret_cast<int*>(lds.ring_meta + 2 * NCOMP * kp.ring);
+  lds.bi_oob = lds.bi_A + 2 * kp.ring;
+  lds.firstk = lds.bi_oob + 2 * kp.ring;
+  lds.seq = reinterpret_cast<uint32_t*>(dyn_smem + kp.lds_meta_bytes);
+  lds.meta_log = nullptr;
+  void* ring_mem = (void*)(__attribute__((address_space(1))) char*)(uintptr_t)uni64(pc.ring_mem);  // (a global pointer, not a generic one: the row probes stay global_load)
+  const rsrc_t ring_rs = make_rsrc(ring_mem, kp.ring_slot_stride);
+  __syncthreads();  // everyone has read pctx before the search rewrites parts of it
+  Breakpoint bp;
+  const int rc = find_breakpoint<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, cb, ce, score_remaining, known, force_single, bp, lstats);
+  if (threadIdx.x == 0) sh.bp_out = bp;
+  __syncthreads();
   return rc;
 }
 
@@ -2540,7 +2661,34 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
         int rc = BP_OK;
         for (int attempt = 0; attempt < 2; ++attempt) {  // (one call site: the search stays inlined)
           // second attempt: the searches met before the I/D history was being kept -- once more, step by step from the start
-          rc = find_breakpoint<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, t.cb, t.ce, t.score_remaining, t.known, attempt == 1, bp, lstats);
+          if (tid == 0) {  // the search's inputs (find_breakpoint_fn reads them back after a barrier)
+            PassCtx& pc = sh.pctx;
+            pc.ring_mem = (unsigned long long)(uintptr_t)ring_mem;
+            pc.ring_bytes = (unsigned long long)kp.ring_slot_stride;
+            pc.P[0] = (unsigned long long)(uintptr_t)cx.P[0];
+            pc.P[1] = (unsigned long long)(uintptr_t)cx.P[1];
+            pc.T[0] = (unsigned long long)(uintptr_t)cx.T[0];
+            pc.T[1] = (unsigned long long)(uintptr_t)cx.T[1];
+            pc.Pw = (unsigned long long)(uintptr_t)cx.Pw;
+            pc.Tw = (unsigned long long)(uintptr_t)cx.Tw;
+            pc.ring = kp.ring;
+            pc.wcap = kp.wcap;
+            pc.x = pn.x; pc.o1 = pn.o1; pc.e1 = pn.e1; pc.o2 = pn.o2; pc.e2 = pn.e2;
+            pc.lds_meta_bytes = kp.lds_meta_bytes;
+            pc.lds_seq_bytes = kp.lds_seq_bytes;
+            pc.chain_max = kp.chain_max;
+            pc.multi_T = kp.multi_T;
+            pc.plen = plen; pc.tlen = tlen;
+            pc.seq_mode = cx.seq_mode; pc.p_w0 = cx.p_w0; pc.t_w0 = cx.t_w0; pc.p_bit = cx.p_bit; pc.t_bit = cx.t_bit;
+            pc.pb_abs = cx.pb_abs; pc.tb_abs = cx.tb_abs;
+          }
+          __syncthreads();
+          rc = uni(find_breakpoint_fn<P2, OffT>((unsigned)(uintptr_t)&sh, (unsigned)(uintptr_t)lds.ring_meta, (unsigned)(uintptr_t)lstats,
+                                                t.cb, t.ce, t.score_remaining, t.known, attempt == 1 ? 1 : 0));
+          if (rc == BP_OK) {
+            bp.score = uni(sh.bp_out.score); bp.sf = uni(sh.bp_out.sf); bp.sr = uni(sh.bp_out.sr); bp.kf = uni(sh.bp_out.kf);
+            bp.kr = uni(sh.bp_out.kr); bp.off_f = uni(sh.bp_out.off_f); bp.off_r = uni(sh.bp_out.off_r); bp.comp = uni(sh.bp_out.comp);
+          }
           if (rc != BP_RESTART) break;
           if (tid == 0) lstats[STAT_RESTARTS] += 1;
         }
