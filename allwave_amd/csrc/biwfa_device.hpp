@@ -14,7 +14,13 @@
 //     meet-in-the-middle overlap test reads both wavefronts with aligned vector loads;
 //   * wavefront rows live in a per-workgroup arena in HBM (ring of `ring` rows per component and
 //     direction), row metadata (lo/hi, max antidiagonal) in LDS;
-//   * one workgroup barrier per score step, forward and reverse steps fused.
+//   * while the two searches are far apart a window advances 5 scores per pass (15 with chained sweeps
+//     under the default scores) with the I/D rows -- and the previous sweeps' M rows -- in registers
+//     (compute_rows_multi); near the meeting point and in trimmed rows every score is a step of its
+//     own (compute_row), forward and reverse steps fused, one workgroup barrier per step;
+//   * the far-apart phase (multi_phase), the base case's passes (base_phase), the breakpoint search
+//     (find_breakpoint_fn) and the trimmed-hull search (trim_pass_fn) are real functions with register
+//     files of their own; their inputs travel through LDS (Shared::pctx).
 //
 // The header is compiled once per workgroup size: AWV_WG = 64 (one wave per pair: the throughput
 // kernel) and AWV_WG = 256 (four waves share a pair's rows: small batches and very expensive pairs),
