@@ -53,6 +53,17 @@ constexpr int NCOMP = 5;
 constexpr int32_t OFF_NULL = INT32_MIN / 2;
 constexpr int32_t NULLISH = INT32_MIN / 4;    // any value below is a NULL(+n)
 constexpr int32_t NULL16 = -16384;            // NULL as stored in 16-bit rows (NULL16 + NULL16 and NULL16 + tlen + 1 stay negative)
+// AWV_WIDE16: 16-bit rows for pairs of which only the SHORTER sequence fits 16 bits (forced-gap pairs: 2 kbp against
+// 45 kbp).  A cell on diagonal k then stores w = h - max(k, 0) = min(h, v) <= min(plen, tlen) instead of the text
+// offset h, and the row metadata (diagonals up to the longer length) stays 32-bit.  Within a diagonal w orders like
+// h, so every max() of the recurrences is unchanged; across diagonals an insertion adds 1 only where k <= 0 (source
+// diagonal k - 1 < 0) and a deletion only where k >= 0; a cell is inside the matrix <=> 0 <= w <= min(plen + k,
+// tlen - k, plen, tlen).  Everything outside the packed arithmetic sees h again (off_load1 / decode4 take k).
+#ifdef AWV_WIDE16
+constexpr bool WENC = true;
+#else
+constexpr bool WENC = false;
+#endif
 enum { C_M = 0, C_I1 = 1, C_I2 = 2, C_D1 = 3, C_D2 = 4 };
 constexpr int FALLBACK_MIN_SCORE = 250;
 constexpr int FALLBACK_MIN_LENGTH = 100;
@@ -143,7 +154,11 @@ struct Breakpoint { int score, sf, sr, kf, kr, off_f, off_r, comp; };
 
 struct alignas(4) RowMeta16 { int16_t lo, hi; };  // (one 32-bit LDS access, also where the compiler cannot see the base's alignment)  // |k| < 32760 whenever 16-bit rows are in use; empty = {1, 0}
 template <typename OffT> struct MetaTraits;
+#ifdef AWV_WIDE16
+template <> struct MetaTraits<int16_t> { typedef RowMeta Stored; };
+#else
 template <> struct MetaTraits<int16_t> { typedef RowMeta16 Stored; };
+#endif
 template <> struct MetaTraits<int32_t> { typedef RowMeta Stored; };
 __device__ __forceinline__ RowMeta meta_load(const RowMeta16* p) {
   const RowMeta16 m = *p;
@@ -277,11 +292,28 @@ template <typename OffT> struct OffTraits;
 template <> struct OffTraits<int32_t> { static constexpr int VEC = 4; };
 template <> struct OffTraits<int16_t> { static constexpr int VEC = 4; };
 
+template <typename OffT> constexpr bool wenc_of() { return WENC && sizeof(OffT) == 2; }
+// one stored cell of diagonal k as a text offset (OFF_NULL for a NULL)
 template <typename OffT>
-__device__ __forceinline__ int32_t off_load1(const OffT* p) {
+__device__ __forceinline__ int32_t off_load1(const OffT* p, int k) {
   const int32_t v = (int32_t)*p;
-  if (sizeof(OffT) == 2) return v < 0 ? OFF_NULL : v;
+  if (sizeof(OffT) == 2) return v < 0 ? OFF_NULL : (wenc_of<OffT>() ? v + max(k, 0) : v);
   return v;
+}
+// an unpacked lane vector whose element j lies on diagonal k0 + j: stored form -> text offsets (negative = NULL stays)
+template <typename OffT>
+__device__ __forceinline__ void decode4(int32_t (&a)[4], int k0) {
+  if constexpr (wenc_of<OffT>()) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = a[j] < 0 ? a[j] : a[j] + max(k0 + j, 0);
+  }
+}
+// the largest stored value inside the matrix on diagonal k (-1: the diagonal lies outside), `cap` = min(plen, tlen)
+__device__ __forceinline__ int wenc_max(int k, int plen, int tlen, int cap) {
+  int r;
+  const int x = min(plen + k, tlen - k);
+  asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(x), "s"(cap));
+  return r;
 }
 
 // Buffer addressing for the hot row accesses: one SGPR descriptor per arena, an SGPR byte offset
@@ -611,8 +643,14 @@ __device__ __forceinline__ void extend_cells_n(const Lds<OffT>& lds, const SubCt
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     const bool ok = m[j] >= 0;
-    vv[j] = ok ? m[j] - (k0 + (j & 3)) : 0;
-    hh[j] = ok ? m[j] : 0;
+    if constexpr (wenc_of<OffT>()) {  // m holds w = min(h, v): v = w + max(-k, 0), h = w + max(k, 0)
+      const int k = k0 + (j & 3);
+      vv[j] = ok ? m[j] + max(-k, 0) : 0;
+      hh[j] = ok ? m[j] + max(k, 0) : 0;
+    } else {
+      vv[j] = ok ? m[j] - (k0 + (j & 3)) : 0;
+      hh[j] = ok ? m[j] : 0;
+    }
     rr[j] = ok ? min(plen - vv[j], tlen - hh[j]) : 0;
   }
   // uniform branches hoisted out of the per-cell code so the probes stay back to back
@@ -633,7 +671,8 @@ __device__ __forceinline__ void extend_cells_n(const Lds<OffT>& lds, const SubCt
         const bool more = nn[j] == PROBE_FIRST && rr[j] > PROBE_FIRST;
         m[j] += min(nn[j], rr[j]);  // rr == 0 for NULL cells: unchanged
         if (more) {
-          const int v = m[j] - (k0 + (j & 3)), h = m[j];
+          const int v = wenc_of<OffT>() ? m[j] + max(-(k0 + (j & 3)), 0) : m[j] - (k0 + (j & 3));
+          const int h = wenc_of<OffT>() ? m[j] + max(k0 + (j & 3), 0) : m[j];
           m[j] += dir == 0 ? extend_lcp_packed<0>(seq, cx, v, h, ext_iters) : extend_lcp_packed<1>(seq, cx, v, h, ext_iters);
         }
       }
@@ -660,7 +699,8 @@ __device__ __forceinline__ void extend_cells_n(const Lds<OffT>& lds, const SubCt
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       if (cont & (1u << j)) {
-        const int v = m[j] - (k0 + (j & 3)), h = m[j];
+        const int v = wenc_of<OffT>() ? m[j] + max(-(k0 + (j & 3)), 0) : m[j] - (k0 + (j & 3));
+        const int h = wenc_of<OffT>() ? m[j] + max(k0 + (j & 3), 0) : m[j];
         if (packed) m[j] += dir == 0 ? extend_lcp_packed<0>(seq, cx, v, h, ext_iters) : extend_lcp_packed<1>(seq, cx, v, h, ext_iters);
         else m[j] += extend_lcp(Pp, Tp, v, h, plen, tlen, ext_iters);
       }
@@ -712,6 +752,7 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
   const int tI2 = P2 ? row_off<BASE, OffT>(kp, dir, C_I2, score) : 0;
   const int tD2 = P2 ? row_off<BASE, OffT>(kp, dir, C_D2, score) : 0;
   const int plen = cx.plen, tlen = cx.tlen;
+  const int vcap = wenc_of<OffT>() ? min(plen, tlen) : tlen;  // largest stored value inside the matrix
   const int colLo = lo - kmin, colHi = hi - kmin;
   int lane_maxak = 0;
   bool lane_oob = false;
@@ -816,7 +857,7 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
       auto as2 = [](unsigned w) { return __builtin_bit_cast(s2, w); };
       auto asu = [](s2 v) { return __builtin_bit_cast(unsigned, v); };
       const s2 one = {1, 1};
-      const short tl1 = (short)(tlen + 1);
+      const short tl1 = (short)(vcap + 1);
       const s2 tlen1 = {tl1, tl1};
       const us2 null_u = {(unsigned short)NULL16, (unsigned short)NULL16};
       // what buf_store_vec does per element, v < 0 ? NULL16 : min(v, tlen + 1), in two packed ops:
@@ -841,14 +882,18 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
       RawVec<OffT> oI1, oD1, oI2, oD2;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const s2 ins1 = as2(sI1.w[r]) + one;
-        const s2 del1 = as2(sD1.w[r]);
+        // AWV_WIDE16 (stored w = h - max(k, 0)): an insertion into diagonal k adds 1 only for k <= 0, a deletion only for k >= 0
+        const int ka = k0 + 2 * r;
+        const s2 incI = WENC ? s2{(short)(ka <= 0), (short)(ka + 1 <= 0)} : one;
+        const s2 incD = {(short)(ka >= 0), (short)(ka + 1 >= 0)};
+        const s2 ins1 = as2(sI1.w[r]) + incI;
+        const s2 del1 = WENC ? as2(sD1.w[r]) + incD : as2(sD1.w[r]);
         s2 ins = ins1, del = del1;
         oI1.w[r] = asu(canon(ins1));
         oD1.w[r] = asu(canon(del1));
         if (P2) {
-          const s2 ins2 = as2(sI2.w[r]) + one;
-          const s2 del2 = as2(sD2.w[r]);
+          const s2 ins2 = as2(sI2.w[r]) + incI;
+          const s2 del2 = WENC ? as2(sD2.w[r]) + incD : as2(sD2.w[r]);
           ins = __builtin_elementwise_max(ins, ins2);
           del = __builtin_elementwise_max(del, del2);
           oI2.w[r] = asu(canon(ins2));
@@ -859,7 +904,7 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int mm = (int)mm2[e];
-          const int hmax = clamp_from_m1(hbase + 2 * r + e, tlen);
+          const int hmax = WENC ? wenc_max(ka + e, plen, tlen, vcap) : clamp_from_m1(hbase + 2 * r + e, tlen);
           lane_oob |= lane_on && mm > hmax;
           m[2 * r + e] = (mm > hmax || mm < 0 || !lane_on) ? OFF_NULL : mm;
         }
@@ -926,9 +971,9 @@ __device__ __forceinline__ int compute_row(const KParams& kp, Shared& sh, const 
     int it_maxak = 0;
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
-      if (m[j] >= 0) it_maxak = max(it_maxak, 2 * m[j] - (k0 + j));
+      if (m[j] >= 0) it_maxak = max(it_maxak, wenc_of<OffT>() ? 2 * m[j] + abs(k0 + j) : 2 * m[j] - (k0 + j));  // h + v
     lane_maxak = max(lane_maxak, it_maxak);
-    if (lane_on) buf_store_vec<OffT>(rs, voff, tM, m, tlen);
+    if (lane_on) buf_store_vec<OffT>(rs, voff, tM, m, vcap);
     PROF_DRAIN();
     PROF_ADD_L(STAT_T_CR_STORE, tc3);
   }
@@ -1097,7 +1142,9 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
   auto as2 = [](unsigned w) { return __builtin_bit_cast(s2, w); };
   auto asu = [](s2 v) { return __builtin_bit_cast(unsigned, v); };
   const s2 one = {1, 1};
-  const short tl1 = (short)(tlen + 1);
+  constexpr bool WE = wenc_of<OffT>();  // AWV_WIDE16: stored w = h - max(k, 0)
+  const int vcap = WE ? min(plen, tlen) : tlen;  // largest stored value inside the matrix
+  const short tl1 = (short)(vcap + 1);
   const s2 tlen1 = {tl1, tl1};
   const us2 null_u = {(unsigned short)NULL16, (unsigned short)NULL16};
   auto canon = [&](unsigned w) {  // v < 0 ? NULL16 : min(v, tlen + 1), per half
@@ -1171,8 +1218,16 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
     int hmaxv[VEC], hminv[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      hmaxv[j] = clamp_from_m1(plen + k0 + j, tlen);
-      hminv[j] = max(k0 + j, 0);
+      hmaxv[j] = WE ? wenc_max(k0 + j, plen, tlen, vcap) : clamp_from_m1(plen + k0 + j, tlen);
+      hminv[j] = WE ? 0 : max(k0 + j, 0);
+    }
+    // AWV_WIDE16: an insertion into diagonal k adds 1 only for k <= 0, a deletion only for k >= 0
+    s2 incI[2], incD[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int ka = k0 + 2 * r;
+      incI[r] = WE ? s2{(short)(ka <= 0), (short)(ka + 1 <= 0)} : one;
+      incD[r] = s2{(short)(ka >= 0), (short)(ka + 1 >= 0)};
     }
 #pragma nounroll
     for (int h = 0; h < nh; ++h) {
@@ -1250,14 +1305,14 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             }
   #pragma unroll
             for (int r = 0; r < 2; ++r) {
-              const s2 ins1 = as2(sI1.w[r]) + one;
-              const s2 del1 = as2(sD1.w[r]);
+              const s2 ins1 = as2(sI1.w[r]) + incI[r];
+              const s2 del1 = WE ? as2(sD1.w[r]) + incD[r] : as2(sD1.w[r]);
               s2 ins = ins1, del = del1;
               nI1.w[r] = asu(ins1);
               nD1.w[r] = asu(del1);
               if (P2) {
-                const s2 ins2 = as2(sI2.w[r]) + one;
-                const s2 del2 = as2(sD2.w[r]);
+                const s2 ins2 = as2(sI2.w[r]) + incI[r];
+                const s2 del2 = WE ? as2(sD2.w[r]) + incD[r] : as2(sD2.w[r]);
                 ins = __builtin_elementwise_max(ins, ins2);
                 del = __builtin_elementwise_max(del, del2);
                 nI2.w[r] = asu(ins2);
@@ -1324,7 +1379,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             } else {
               val = (int)(je == 0 ? ev.w[0] : je == 1 ? ev.w[1] : je == 2 ? ev.w[2] : ev.w[3]);
             }
-            if (__any(mine && val >= tlen)) reach_mask |= 1u << (tb + t);
+            if (__any(mine && val >= (WE ? vcap : tlen))) reach_mask |= 1u << (tb + t);  // (the end cell's diagonal is tlen - plen: h = tlen <=> w = min(plen, tlen))
           }
           PROF_DRAIN();
           PROF_ADD_L(STAT_T_CR_ALU, tm1);
@@ -1337,8 +1392,8 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             V mv;
             int c[VEC];
             if constexpr (W16) {
-              mv.w[0] = pack_canon16(m[0], m[1], tlen + 1, c[0], c[1]);
-              mv.w[1] = pack_canon16(m[2], m[3], tlen + 1, c[2], c[3]);
+              mv.w[0] = pack_canon16(m[0], m[1], vcap + 1, c[0], c[1]);
+              mv.w[1] = pack_canon16(m[2], m[3], vcap + 1, c[2], c[3]);
             } else {
 #pragma unroll
               for (int j = 0; j < VEC; ++j) {
@@ -1351,7 +1406,10 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
               // -16384 there, so 2 c - k stays far below any real antidiagonal without a test per cell; cells outside
               // the step's hull are NULL, and the halo lanes' sums are dropped at the end.
 #pragma unroll
-              for (int j = 0; j < VEC; ++j) lane_maxak = max(lane_maxak, (c[j] - (k0 + j)) + c[j]);
+              for (int j = 0; j < VEC; ++j) {
+                if constexpr (WE) lane_maxak = max(lane_maxak, 2 * m[j] + abs(k0 + j));  // h + v = 2 w + |k| (a NULL is OFF_NULL in m: far below 0; |k| may exceed 16384, so not from the clamped value)
+                else lane_maxak = max(lane_maxak, (c[j] - (k0 + j)) + c[j]);
+              }
             }
             if (lane_on) st(row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t), voff, mv);
             if (CHAIN) Mnew[t] = mv;
@@ -1360,7 +1418,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             const int je = mp.end_col - c0;
             const bool mine = lane_on && je >= 0 && je < VEC;
             const int val = je == 0 ? m[0] : je == 1 ? m[1] : je == 2 ? m[2] : m[3];
-            if (__any(mine && val >= tlen)) reach_mask |= 1u << (tb + t);
+            if (__any(mine && val >= (WE ? vcap : tlen))) reach_mask |= 1u << (tb + t);
           }
           PROF_DRAIN();
           PROF_ADD_L(STAT_T_CR_STORE, tm3);
@@ -1704,7 +1762,7 @@ __device__ __forceinline__ void trim_pass(const KParams& kp, const SubCtx& cx, v
     const int k = col + kmin;
     bool inb = false;
     if (col >= colLo && col <= colHi) {
-      const int32_t v = off_load1<OffT>(row_ptr<BASE, OffT>(kp, mem, dir, c, score) + col);
+      const int32_t v = off_load1<OffT>(row_ptr<BASE, OffT>(kp, mem, dir, c, score) + col, k);
       inb = (uint32_t)v <= (uint32_t)tlen && (uint32_t)(v - k) <= (uint32_t)plen;
     }
     return __ballot(inb);
@@ -1819,8 +1877,9 @@ __device__ __forceinline__ int bt_fetch(const KParams& kp, const RowMeta* base_m
   if (score < 0 || score > max_score) return -1;
   const RowMeta m = base_meta[score * NCOMP + comp];
   if (k < m.lo || k > m.hi) return -1;
-  const int32_t v = (int32_t)hist[((size_t)score * NCOMP + comp) * (size_t)kp.wb_cap + (k - kmin)];
+  int32_t v = (int32_t)hist[((size_t)score * NCOMP + comp) * (size_t)kp.wb_cap + (k - kmin)];
   if (v < 0) return -1;
+  if (wenc_of<OffT>()) v += max(k, 0);  // stored form -> text offset
   return ((v + add) << 4) | type;
 }
 
@@ -1890,7 +1949,7 @@ __device__ __forceinline__ int base_align(const KParams& kp, Shared& sh, const L
     // termination (wavefront_termination_end2end): end component reaches (plen, tlen)
     const RowMeta me = get_meta<OffT>(kp, lds, 0, ce, score);
     if (k_end >= me.lo && k_end <= me.hi) {
-      const int32_t v = uni(off_load1<OffT>(hist + ((size_t)score * NCOMP + ce) * (size_t)kp.wb_cap + (k_end - kmin)));
+      const int32_t v = uni(off_load1<OffT>(hist + ((size_t)score * NCOMP + ce) * (size_t)kp.wb_cap + (k_end - kmin), k_end));
       if (v >= tlen) break;
     }
     if (MULTI_BUILD && multi_open && !dirty) {
@@ -2153,6 +2212,11 @@ __device__ __forceinline__ void bialign_overlap(const KParams& kp, Shared& sh, c
           int32_t a0[VEC], a1[VEC];
           unpack_raw<OffT>(g0[u], a0);
           unpack_raw<OffT>(g1[u], a1);
+          {
+            const int c0 = ((cg + u) << 8) + lane * VEC;
+            decode4<OffT>(a0, c0 + kmin0);
+            decode4<OffT>(a1, Cm - c0 - (VEC - 1) + kmin1);
+          }
           bool reach = false;
 #pragma unroll
           for (int j = 0; j < VEC; ++j) reach = reach || (a0[j] >= 0 && a1[VEC - 1 - j] >= 0 && a0[j] + a1[VEC - 1 - j] >= tlen);
@@ -2177,6 +2241,8 @@ __device__ __forceinline__ void bialign_overlap(const KParams& kp, Shared& sh, c
         int32_t g0[VEC], g1[VEC];
         unpack_raw<OffT>(buf_load_raw<OffT>(ring_rs, c0 * ESZ, so0M), g0);
         unpack_raw<OffT>(buf_load_raw<OffT>(ring_rs, (Cm - c0 - (VEC - 1)) * ESZ, so1M), g1);
+        decode4<OffT>(g0, c0 + kmin0);
+        decode4<OffT>(g1, Cm - c0 - (VEC - 1) + kmin1);
         bool reach = false;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) reach = reach || (g0[j] >= 0 && g1[VEC - 1 - j] >= 0 && g0[j] + g1[VEC - 1 - j] >= tlen);
@@ -2196,6 +2262,8 @@ __device__ __forceinline__ void bialign_overlap(const KParams& kp, Shared& sh, c
         int32_t v0[VEC], v1[VEC];
         unpack_raw<OffT>(q0[c], v0);
         unpack_raw<OffT>(q1[c], v1);
+        decode4<OffT>(v0, c0 + kmin0);
+        decode4<OffT>(v1, Cm - c0 - (VEC - 1) + kmin1);
         int first = VEC;
 #pragma unroll
         for (int j = VEC - 1; j >= 0; --j) {
@@ -2237,8 +2305,8 @@ __device__ __forceinline__ void bialign_overlap(const KParams& kp, Shared& sh, c
     if (k0 == INT_MAX) return;
     if (s0 + si - gap_open >= bp.score) return;
     const int k1 = D - k0;
-    const int32_t h0 = uni(off_load1<OffT>(row_ptr<false, OffT>(kp, ring_mem, d0, c, s0) + (k0 - kmin0)));
-    const int32_t h1 = uni(off_load1<OffT>(row_ptr<false, OffT>(kp, ring_mem, d1, c, si) + (k1 - kmin1)));
+    const int32_t h0 = uni(off_load1<OffT>(row_ptr<false, OffT>(kp, ring_mem, d0, c, s0) + (k0 - kmin0), k0));
+    const int32_t h1 = uni(off_load1<OffT>(row_ptr<false, OffT>(kp, ring_mem, d1, c, si) + (k1 - kmin1), k1));
     if (fwd) { bp.sf = s0; bp.sr = si; bp.kf = k0; bp.kr = k1; bp.off_f = h0; bp.off_r = h1; }
     else { bp.sf = si; bp.sr = s0; bp.kf = k1; bp.kr = k0; bp.off_f = h1; bp.off_r = h0; }
     bp.score = s0 + si - gap_open;

@@ -29,6 +29,20 @@
 #include "biwfa_device.hpp"
 #undef AWV_NS
 #undef AWV_WG
+// awvw_m:: / awvx_m:: the same two with AWV_WIDE16: 16-bit rows for pairs of which only the shorter sequence fits 16
+// bits (cells stored as min(h, v), 32-bit row metadata) -- only their 16-bit-row kernels are used
+#define AWV_WIDE16 1
+#define AWV_NS awvw_m
+#define AWV_WG 256
+#include "biwfa_device.hpp"
+#undef AWV_NS
+#undef AWV_WG
+#define AWV_NS awvx_m
+#define AWV_WG 1024
+#include "biwfa_device.hpp"
+#undef AWV_NS
+#undef AWV_WG
+#undef AWV_WIDE16
 
 #include <algorithm>
 #include <chrono>
@@ -440,7 +454,10 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     // One group of the batch = one kernel flavour: `wide` pairs get a 256-thread workgroup each (four
     // waves deal a row's windows among themselves), the others one wave each.
     auto run_group = [&](std::vector<int32_t> hq, std::vector<int32_t> ht, std::vector<int32_t> hrc, std::vector<uint64_t> hoff,
-                         std::vector<int64_t> amap, int waves, bool narrow, int g_maxsum, int g_maxlen, bool reserve_only) -> int {
+                         std::vector<int64_t> amap, int waves, int width, int g_maxsum, int g_maxlen, bool reserve_only) -> int {
+    // width: 0 = 16-bit rows (both lengths < 32760), 1 = 32-bit rows, 2 = 16-bit rows holding min(h, v) with 32-bit
+    // row metadata (AWV_WIDE16: only the shorter length < 32760)
+    const bool narrow = width != 1, wide_meta = width == 2;
     if (hq.empty()) return AWV_OK;
     const int wg = waves == 1 ? AWV_THRU_WG : 64 * waves;
     const int nslots_g = e->cfg.workgroups > 0 ? std::max(1, e->cfg.workgroups / (wg / 64)) : (WAVES_PER_SIMD * 256 / wg) * e->num_cus;
@@ -452,7 +469,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
     // dynamic LDS = ring metadata (16-bit entries with 16-bit rows) + staging of the 2-bit packed
     // sequences: what the largest pair needs, within 160 KB / (16 waves per CU) per workgroup;
     // sub-problems that do not fit read global memory instead
-    const size_t lds_meta = lds_meta_bytes(narrow ? sizeof(RowMeta16) : sizeof(RowMeta));
+    const size_t lds_meta = lds_meta_bytes(narrow && !wide_meta ? sizeof(RowMeta16) : sizeof(RowMeta));
     const size_t seq_need = ((((size_t)g_maxlen + 15) / 16 + 2) * 2 + 10) * 4;
     const size_t lds_budget = (size_t)(160 * 1024 / (WAVES_PER_SIMD * 256 / wg)) - STATIC_LDS_RESERVE;
     size_t lds_seq = (e->cfg.flags & AWV_F_NO_PACKED_SEQ) ? 0 : (lds_meta < lds_budget ? std::min(seq_need, lds_budget - lds_meta) : 0);
@@ -603,6 +620,17 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       if (waves == 1) {
         if (dp.two_piece) lrc = narrow ? launch(awv::biwfa_align_kernel<true, int16_t>, kp) : launch(awv::biwfa_align_kernel<true, int32_t>, kp);
         else lrc = narrow ? launch(awv::biwfa_align_kernel<false, int16_t>, kp) : launch(awv::biwfa_align_kernel<false, int32_t>, kp);
+      } else if (wide_meta) {
+        static_assert(sizeof(awvw_m::KParams) == sizeof(awv::KParams) && sizeof(awvx_m::KParams) == sizeof(awv::KParams), "same parameter block");
+        if (waves == 4) {
+          awvw_m::KParams kw;
+          std::memcpy(&kw, &kp, sizeof(kw));
+          lrc = dp.two_piece ? launch(awvw_m::biwfa_align_kernel<true, int16_t>, kw) : launch(awvw_m::biwfa_align_kernel<false, int16_t>, kw);
+        } else {
+          awvx_m::KParams kx;
+          std::memcpy(&kx, &kp, sizeof(kx));
+          lrc = dp.two_piece ? launch(awvx_m::biwfa_align_kernel<true, int16_t>, kx) : launch(awvx_m::biwfa_align_kernel<false, int16_t>, kx);
+        }
       } else if (waves == 4) {
         awvw::KParams kw;
         std::memcpy(&kw, &kp, sizeof(kw));
@@ -667,7 +695,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       // (a batch of uneven pairs that fits the machine about once is bound by its longest pairs, not by throughput)
       const bool all_wide = !never_wide && ((e->cfg.flags & AWV_F_FOUR_WAVES) || n <= (int64_t)(WAVES_PER_SIMD * e->num_cus) ||
                                             (skewed && n <= (int64_t)(4 * WAVES_PER_SIMD * e->num_cus)));
-      constexpr int NG = 6;  // group = flavour (0 one wave, 1 four, 2 sixteen) * 2 + (32-bit rows ? 1 : 0)
+      constexpr int NG = 9;  // group = flavour (0 one wave, 1 four, 2 sixteen) * 3 + row width (0: 16-bit, 1: 32-bit, 2: 16-bit min(h, v) rows)
       std::vector<int32_t> q[NG], t[NG], rc[NG];
       std::vector<uint64_t> off[NG];
       std::vector<int64_t> map[NG];
@@ -677,13 +705,17 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       for (int64_t i = 0; i < n; ++i) n_huge += std::abs(s.len[hq[(size_t)i]] - s.len[ht[(size_t)i]]) >= 16384;
       const bool use_sixteen = !never_wide && !(e->cfg.flags & AWV_F_FOUR_WAVES) && n_huge > 0 && n_huge <= (int64_t)e->num_cus;
       const bool force32 = (e->cfg.flags & AWV_F_FORCE_INT32) != 0;
+      const bool no_wide16 = (e->cfg.flags & AWV_F_NO_WIDE16) != 0;
       for (int64_t i = 0; i < n; ++i) {
         const int ql = s.len[hq[(size_t)i]], tl = s.len[ht[(size_t)i]];
         const int dl = std::abs(ql - tl);
-        const bool wide_rows = force32 || std::max(ql, tl) >= 32760;
         int f = (all_wide || (!never_wide && (dl >= 4096 || std::max(ql, tl) >= 32760))) ? 1 : 0;
         if (use_sixteen && dl >= 16384) f = 2;  // a forced gap that long: rows hundreds of windows wide
-        const int g = f * 2 + (wide_rows ? 1 : 0);
+        // row width: every stored value must fit 16 bits -- text offsets (both lengths short), or min(h, v) when only
+        // the shorter sequence is (the kernels for that exist in the four- and sixteen-wave flavours)
+        int w = force32 || std::max(ql, tl) >= 32760 ? 1 : 0;
+        if (w == 1 && !force32 && !no_wide16 && f >= 1 && std::min(ql, tl) < 32760) w = 2;
+        const int g = f * 3 + w;
         q[g].push_back(hq[(size_t)i]); t[g].push_back(ht[(size_t)i]); rc[g].push_back(hrc[(size_t)i]); off[g].push_back(hoff[(size_t)i]);
         map[g].push_back(amap.empty() ? i : amap[(size_t)i]);
         gsum[g] = std::max(gsum[g], ql + tl);
@@ -697,20 +729,20 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
         for (int g = 0; g < NG; ++g) {
           demand[g] = {0, g};
           if (q[g].empty()) continue;
-          const int wv = waves_of[g / 2];
+          const int wv = waves_of[g / 3];
           const int wgx = wv == 1 ? AWV_THRU_WG : 64 * wv;
           const int64_t slots = std::min<int64_t>((WAVES_PER_SIMD * 256 / wgx) * e->num_cus, (int64_t)q[g].size());
-          demand[g].first = (size_t)slots * (size_t)gsum[g] * ((g & 1) ? 4 : 2);
+          demand[g].first = (size_t)slots * (size_t)gsum[g] * ((g % 3) == 1 ? 4 : 2);
         }
         std::sort(demand, demand + NG, [](const std::pair<size_t, int>& a, const std::pair<size_t, int>& b) { return a.first > b.first; });
         for (int k = 0; k < NG; ++k) {
           const int g = demand[k].second;
           if (q[g].empty()) continue;
-          if (int rcg = run_group(q[g], t[g], rc[g], off[g], map[g], waves_of[g / 2], !(g & 1), gsum[g], glen[g], true)) return rcg;
+          if (int rcg = run_group(q[g], t[g], rc[g], off[g], map[g], waves_of[g / 3], g % 3, gsum[g], glen[g], true)) return rcg;
         }
       }
       for (int g = NG - 1; g >= 0; --g)
-        if (int rcg = run_group(std::move(q[g]), std::move(t[g]), std::move(rc[g]), std::move(off[g]), std::move(map[g]), waves_of[g / 2], !(g & 1), gsum[g], glen[g], false)) return rcg;
+        if (int rcg = run_group(std::move(q[g]), std::move(t[g]), std::move(rc[g]), std::move(off[g]), std::move(map[g]), waves_of[g / 3], g % 3, gsum[g], glen[g], false)) return rcg;
     }
     const bool want_cigar = sink && !(e->cfg.flags & AWV_F_KEEP_ON_DEVICE);
     lap("results on host");

@@ -22,6 +22,7 @@ AWV_F_FOUR_WAVES = 16
 AWV_F_NO_ARENA_PROBE = 32
 AWV_F_SINGLE_STEP = 64
 AWV_F_NO_CHAIN = 128
+AWV_F_NO_WIDE16 = 256
 
 #: every symbol include/allwave_hip.h declares
 EXPORTS = ("awv_abi_version", "awv_last_error", "awv_engine_create", "awv_engine_destroy",

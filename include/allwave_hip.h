@@ -76,7 +76,9 @@ typedef struct {
 } awv_engine_config;
 
 #define AWV_F_KEEP_ON_DEVICE 1 /* do not copy CIGARs back (kernel-only measurements) */
-#define AWV_F_FORCE_INT32 2    /* always use 32-bit wavefront rows (default: 16-bit when lengths < 32760) */
+#define AWV_F_FORCE_INT32 2    /* always use 32-bit wavefront rows (default: 16-bit when lengths < 32760, and -- in the
+                                  four- and sixteen-wave flavours -- when only the shorter length is: rows of min(h, v)) */
+#define AWV_F_NO_WIDE16 256    /* 32-bit rows whenever the longer sequence has 32760 bases or more (no min(h, v) rows) */
 #define AWV_F_NO_PACKED_SEQ 4  /* never stage 2-bit packed sequences in LDS (raw-byte probes from HBM only) */
 #define AWV_F_ONE_WAVE 8       /* always one wave per pair (default: four waves per pair for small batches, long sequences and unequal lengths, sixteen for a few very unequal pairs) */
 #define AWV_F_FOUR_WAVES 16    /* always four waves per pair */

@@ -26,7 +26,8 @@ elif sel == "shorttext":
     pairs = pairs[(ql >= 32760) & (tl < 32760)]
 elif sel == "shortpattern":
     pairs = pairs[(ql < 32760) & (tl >= 32760)]
-pairs = np.ascontiguousarray(pairs)
+stride = int(os.environ.get("C45_STRIDE", "1"))  # every stride-th pair of the selection (profiling runs)
+pairs = np.ascontiguousarray(pairs[::stride])
 e = ffi.Engine(flags=flags | ffi.AWV_F_KEEP_ON_DEVICE)
 e.set_sequences((data, offs))
 t0 = time.time()

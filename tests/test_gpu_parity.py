@@ -421,6 +421,47 @@ def test_config5_real_lengths(oracle):
         assert oracle.fnv1a(gcigs[i]) == int(ores["cigar_hash"][i]), ("config 5 pair", tuple(sub[i]), int(lens[sub[i, 0]]), int(lens[sub[i, 1]]))
 
 
+@pytest.mark.parametrize("scores", [DEFAULT_2P, (0, 4, 6, 2), (0, 3, 5, 1, 20, 1), EDIT])
+def test_wide16_rows(oracle, scores):
+    """Pairs whose LONGER sequence has 32760 bases or more while the shorter one fits 16 bits run on 16-bit rows that
+    hold min(h, v) per cell (AWV_WIDE16: 32-bit row metadata, insertions / deletions add 1 on one side of the main
+    diagonal only).  Forced gaps of tens of kbp in both roles (short text, short pattern), a related and an unrelated
+    short sequence, the boundary length 32759 and reverse-complemented queries: against the oracle bit for bit, and
+    field by field against the 32-bit-row kernels on the same pairs."""
+    from allwave_amd import ffi
+    rng = random.Random(32760 + len(scores))
+    comp = {65: 84, 84: 65, 67: 71, 71: 67}
+    root = rand_seq(rng, 41000)
+    long_a = root[:40000]
+    long_b = mutate(root, 0.03, rng)[:36000]
+    short_rel = mutate(root[18000:21000], 0.05, rng)      # 3 kbp from the middle: forced gaps on both sides
+    short_unrel = rand_seq(rng, 2000)
+    edge = mutate(root, 0.02, rng)[:32759]                # the longest sequence 16-bit values can hold
+    seqs = [long_a, long_b, short_rel, short_unrel, edge, bytes(comp[b] for b in reversed(short_rel))]
+    pairs = [(0, 2, 0), (2, 0, 0), (1, 3, 0), (3, 1, 0), (0, 4, 0), (4, 1, 0), (5, 0, 1), (0, 5, 0)]
+    out = {}
+    for name, flags in (("wide16", 0), ("rows32", ffi.AWV_F_NO_WIDE16)):
+        e = ffi.Engine(flags=flags)
+        try:
+            e.set_sequences(seqs)
+            out[name] = e.align_pairs(scores, pairs)
+        finally:
+            e.close()
+    (res, cigs), (res32, cigs32) = out["wide16"], out["rows32"]
+    assert (res["status"] == 0).all() and (res32["status"] == 0).all()
+    for f in res.dtype.names:
+        assert (res[f] == res32[f]).all(), f
+    assert cigs == cigs32
+    # the oracle's thread-pool driver on the same pairs (the reverse-complemented query is sequence 2 itself)
+    data = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in seqs])]).astype(np.uint64)
+    opairs = np.asarray([(2 if rc else a, b) for a, b, rc in pairs], dtype=np.int32)
+    _, ores, _, _ = oracle.all_pairs(data, offs, opairs, scores, nthreads=min(8, os.cpu_count() or 1))
+    assert (ores["status"] == 0).all()
+    for i in range(len(pairs)):
+        assert res["penalty"][i] == ores["penalty"][i] and oracle.fnv1a(cigs[i]) == int(ores["cigar_hash"][i]), (scores, pairs[i])
+
+
 @pytest.mark.parametrize("length", [32759, 32760])
 def test_row_width_boundary(engine, oracle, length):
     """The longest sequences that still use 16-bit rows (32759) and the shortest that take 32-bit
