@@ -1019,7 +1019,10 @@ constexpr int TMAX = AWV_TMAX;  // steps per sweep (one burst of row loads)
 // of one window run back to back with those rows (and the I/D queues) in registers: per 15 scores a window
 // then loads 6 + 15 + 10 + 5 + 15 (gap-open-2 sources, always from memory) ... see DESIGN.md section 4.
 constexpr int CHAIN_MAX = AWV_CHAIN_MAX;
-constexpr int TMAX32 = 3;  // steps per sweep with 32-bit rows (a lane vector is four registers: 3 x 3 sources + the I/D queues = 60)
+#ifndef AWV_TMAX32
+#define AWV_TMAX32 5
+#endif
+constexpr int TMAX32 = AWV_TMAX32;  // steps per sweep with 32-bit rows (their M sources are loaded one step ahead, not all up front)
 constexpr int MSTEPS = 16;  // most steps one pass can cover (a lane table entry per step and per source)
 static_assert(TMAX >= 2 && TMAX <= 8 && TMAX * CHAIN_MAX <= MSTEPS - 1, "pass length");
 
@@ -1235,19 +1238,40 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
       const int tb = h * TM;        // its first step index within the pass
       const int tn = min(TM, Tn - tb);
       const bool own0 = CHAIN && h >= 1, own1 = CHAIN && h >= 2;  // (uniform) M sources 0 / 1 come from registers
-      // ---- all row loads of the sweep, back to back
-      V tap[TM][NT];
+      // ---- 16-bit rows: all row loads of the sweep, back to back (one memory round trip per sweep).  32-bit rows (a lane
+      // vector is four registers; TM x NT of them do not fit): the M sources of a step are loaded one step ahead -- `cur`
+      // feeds step t while `nxt` (step t + 1) is in flight; these kernels are bound by HBM bytes, not by the round trips
+      constexpr int TAPS = W16 ? TM : 1;
+      V tap[TAPS][NT];
 #pragma unroll
-      for (int t = 0; t < TM; ++t)
+      for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int w = 0; w < NT; ++w) tap[t][w] = V{};
-      if (load_on) {
+      auto load_taps = [&](int t, V (&dst)[NT]) {  // M sources of step t (of this sweep), masked to their stored hulls
 #pragma unroll
-        for (int t = 0; t < TM; ++t) {
-          if (t < tn) {
-            if (!own0) tap[t][0] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.x));
-            if (!own1) tap[t][1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o1 - pn.e1));
-            if (P2) tap[t][NT - 1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o2 - pn.e2));
+        for (int w = 0; w < NT; ++w) dst[w] = V{};
+        if (t < tn) {
+          if (load_on) {
+            if (!own0) dst[0] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.x));
+            if (!own1) dst[1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o1 - pn.e1));
+            if (P2) dst[NT - 1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o2 - pn.e2));
+          }
+          if (!interior) {
+            if (!own0) lmask(NS0 + tb + t, dst[0]);
+            if (!own1) lmask(NS0 + 16 + tb + t, dst[1]);
+            if (P2) lmask(NS0 + 32 + tb + t, dst[NT - 1]);
+          }
+        }
+      };
+      if constexpr (W16) {
+        if (load_on) {
+#pragma unroll
+          for (int t = 0; t < TM; ++t) {
+            if (t < tn) {
+              if (!own0) tap[t][0] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.x));
+              if (!own1) tap[t][1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o1 - pn.e1));
+              if (P2) tap[t][NT - 1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o2 - pn.e2));
+            }
           }
         }
       }
@@ -1260,15 +1284,21 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             for (int j = 0; j < E2; ++j) { lmask(2 * E1 + j, qI2[j]); lmask(2 * E1 + E2 + j, qD2[j]); }
           }
         }
+        if constexpr (W16) {
 #pragma unroll
-        for (int t = 0; t < TM; ++t) {
-          if (t < tn) {
-            if (!own0) lmask(NS0 + tb + t, tap[t][0]);
-            if (!own1) lmask(NS0 + 16 + tb + t, tap[t][1]);
-            if (P2) lmask(NS0 + 32 + tb + t, tap[t][NT - 1]);
+          for (int t = 0; t < TM; ++t) {
+            if (t < tn) {
+              if (!own0) lmask(NS0 + tb + t, tap[t][0]);
+              if (!own1) lmask(NS0 + 16 + tb + t, tap[t][1]);
+              if (P2) lmask(NS0 + 32 + tb + t, tap[t][NT - 1]);
+            }
           }
         }
       }
+      V cur[NT], nxt[NT];
+#pragma unroll
+      for (int w = 0; w < NT; ++w) { cur[w] = V{}; nxt[w] = V{}; }
+      if constexpr (!W16) load_taps(0, cur);
       PROF_DRAIN();
       PROF_ADD_L(STAT_T_CR_LOAD, tm0);
       // ---- the steps
@@ -1282,7 +1312,11 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           // chained, the next sweeps); only the productive ones store, count and flag
           const bool in_hull = c0 + VEC > lo_t - kmin && c0 <= hi_t - kmin;
           const bool lane_on = productive && in_hull;
-          V cMx = tap[t][0], cO1 = tap[t][1];
+          if constexpr (!W16) {
+            if (t + 1 < TM) load_taps(t + 1, nxt);
+          }
+          V cMx = W16 ? tap[W16 ? t : 0][0] : cur[0], cO1 = W16 ? tap[W16 ? t : 0][1] : cur[1];
+          const V cO2 = W16 ? tap[W16 ? t : 0][NT - 1] : cur[NT - 1];
           if (CHAIN) {
             if (own0) cMx = Mp1[t];
             if (own1) cO1 = Mp2[t];
@@ -1300,8 +1334,8 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             const V sI1 = shift_from_left(pkmax(cO1, qI1[0])), sD1 = shift_from_right(pkmax(cO1, qD1[0]));
             V sI2{}, sD2{};
             if (P2) {
-              sI2 = shift_from_left(pkmax(tap[t][NT - 1], qI2[0]));
-              sD2 = shift_from_right(pkmax(tap[t][NT - 1], qD2[0]));
+              sI2 = shift_from_left(pkmax(cO2, qI2[0]));
+              sD2 = shift_from_right(pkmax(cO2, qD2[0]));
             }
   #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -1334,8 +1368,8 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             const V rI1 = shift_from_left(qI1[0]), rD1 = shift_from_right(qD1[0]);
             V rO2l{}, rO2r{}, rI2{}, rD2{};
             if (P2) {
-              rO2l = shift_from_left(tap[t][NT - 1]);
-              rO2r = shift_from_right(tap[t][NT - 1]);
+              rO2l = shift_from_left(cO2);
+              rO2r = shift_from_right(cO2);
               rI2 = shift_from_left(qI2[0]);
               rD2 = shift_from_right(qD2[0]);
             }
@@ -1432,6 +1466,10 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             for (int j = 0; j + 1 < E2; ++j) { qI2[j] = qI2[j + 1]; qD2[j] = qD2[j + 1]; }
             qI2[E2 - 1] = nI2;
             qD2[E2 - 1] = nD2;
+          }
+          if constexpr (!W16) {
+#pragma unroll
+            for (int w = 0; w < NT; ++w) cur[w] = nxt[w];
           }
         }
       }

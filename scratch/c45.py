@@ -41,7 +41,7 @@ esz = 2  # bytes per row element where both lengths fit 16 bits; quoted per cell
 print(json.dumps({"config": name, "select": sel, "pairs": len(pairs), "failed_invariants": int((~ok).sum()), "wall_s": round(wall, 2), "kernel_ms": round(st.kernel_ms, 1),
                   "launches": st.launches, "Mbp_s_kernel": round(bp / st.kernel_ms / 1e3, 2), "cell_steps": st.cell_steps,
                   "cell_steps_per_s": st.cell_steps / (st.kernel_ms * 1e-3), "multi_frac": round(st.multi_cell_steps / max(st.cell_steps, 1), 4),
-                  "restarts": st.restarts}), flush=True)
+                  "restarts": st.restarts, "status": {int(k): int(v) for k, v in zip(*np.unique(res["status"], return_counts=True))}}), flush=True)
 e.close()
 # oracle sample
 idx = np.unique(np.linspace(0, len(pairs) - 1, nor).astype(np.int64))

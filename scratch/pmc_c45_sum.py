@@ -32,8 +32,9 @@ for k, d in disp.items():
     d["hbm_TBps"] = (2 * d.get("FETCH_SIZE", 0) + d.get("WRITE_SIZE", 0)) * 1024 / d["s"] / 1e12
     d["waves_per_cu"] = 4 * d.get("SQ_WAVE_CYCLES", 0) / cyc / 256
     print({kk: (round(v, 4) if isinstance(v, float) and v < 1e6 else v) for kk, v in d.items() if kk in ("kernel", "wg", "grid", "s", "valu_frac", "busy_cu_frac", "hbm_TBps", "waves_per_cu", "SQ_WAVES")})
-line = [json.loads(l) for l in open("%s/pmc_%s_3.log" % (O, T)) if l.startswith("{")][0]
-cells = line["cell_steps"]; secs = dur[3]
+logs = [f for f in ("%s/pmc_%s_%d.log" % (O, T, i) for i in (3, 4, 1, 2)) if os.path.exists(f)]
+line = [json.loads(l) for l in open(logs[0]) if l.startswith("{")][0]
+cells = line["cell_steps"]; secs = dur[3] or dur[4] or dur[1]
 hbm = (2 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024
 out = {"what": "%s %s" % (line["config"], line["select"]), "pairs": line["pairs"], "kernel_s_by_pass": dict(dur), "kernel_ms_plain": line["kernel_ms"], "cell_steps": cells,
        "cell_steps_per_s": cells / secs, "multi_frac": line["multi_frac"],
