@@ -1019,6 +1019,10 @@ constexpr int TMAX = AWV_TMAX;  // steps per sweep (one burst of row loads)
 // of one window run back to back with those rows (and the I/D queues) in registers: per 15 scores a window
 // then loads 6 + 15 + 10 + 5 + 15 (gap-open-2 sources, always from memory) ... see DESIGN.md section 4.
 constexpr int CHAIN_MAX = AWV_CHAIN_MAX;
+#ifndef AWV_CHAIN_MAX32
+#define AWV_CHAIN_MAX32 2
+#endif
+constexpr int CHAIN_MAX32 = AWV_CHAIN_MAX32;  // 32-bit rows: a sweep's M rows are 20 registers, so only the previous sweep's are kept
 #ifndef AWV_TMAX32
 #define AWV_TMAX32 5
 #endif
@@ -1114,7 +1118,8 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
   constexpr bool W16 = sizeof(OffT) == 2;  // 16-bit rows: packed arithmetic; 32-bit rows: the same recurrences on 32-bit registers
   static_assert(E1 >= 1 && E1 <= 2 && E2 >= 1 && E2 <= 2, "register-resident I/D depth");
   static_assert(!(BASE && CHAIN), "the base case runs single sweeps");
-  static_assert(W16 || !CHAIN, "chained sweeps: 16-bit rows only (a 32-bit sweep's sources alone fill the registers)");
+  static_assert(W16 || !CHAIN || (TMAX32 == TMAX && CHAIN_MAX32 >= 2 && CHAIN_MAX32 <= 3), "chained 32-bit sweeps are TMAX long");
+  constexpr int CH = W16 ? CHAIN_MAX : CHAIN_MAX32;  // sweeps a pass may chain
   constexpr int NWAVES = WG / 64;
   constexpr int VEC = 4, ESZ = (int)sizeof(OffT);
   constexpr int TM = W16 ? TMAX : TMAX32;  // steps per sweep
@@ -1214,9 +1219,11 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
       }
     }
     // the last two sweeps' own M rows (canonical stored form), what the next sweeps read 5 / 10 scores back
-    V Mp1[CHAIN ? TM : 1], Mp2[CHAIN ? TM : 1];
+    V Mp1[CHAIN ? TM : 1], Mp2[CHAIN && CH >= 3 ? TM : 1];
 #pragma unroll
-    for (int t = 0; t < (CHAIN ? TM : 1); ++t) { Mp1[t] = V{}; Mp2[t] = V{}; }
+    for (int t = 0; t < (CHAIN ? TM : 1); ++t) Mp1[t] = V{};
+#pragma unroll
+    for (int t = 0; t < (CHAIN && CH >= 3 ? TM : 1); ++t) Mp2[t] = V{};
     // per cell, the largest / smallest offset inside the matrix on its diagonal (the same for every step of the pass)
     int hmaxv[VEC], hminv[VEC];
 #pragma unroll
@@ -1237,7 +1244,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
       const int sb = s0 + h * TM;   // this sweep covers scores sb + 1 .. sb + TM
       const int tb = h * TM;        // its first step index within the pass
       const int tn = min(TM, Tn - tb);
-      const bool own0 = CHAIN && h >= 1, own1 = CHAIN && h >= 2;  // (uniform) M sources 0 / 1 come from registers
+      const bool own0 = CHAIN && h >= 1, own1 = CHAIN && CH >= 3 && h >= 2;  // (uniform) M sources 0 / 1 come from registers
       // ---- 16-bit rows: all row loads of the sweep, back to back (one memory round trip per sweep).  32-bit rows (a lane
       // vector is four registers; TM x NT of them do not fit): the M sources of a step are loaded one step ahead -- `cur`
       // feeds step t while `nxt` (step t + 1) is in flight; these kernels are bound by HBM bytes, not by the round trips
@@ -1302,7 +1309,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
       PROF_DRAIN();
       PROF_ADD_L(STAT_T_CR_LOAD, tm0);
       // ---- the steps
-      V Mnew[CHAIN ? TM : 1];
+      V Mnew[CHAIN && W16 ? TM : 1];
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
         if (t < tn) {
@@ -1319,7 +1326,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           const V cO2 = W16 ? tap[W16 ? t : 0][NT - 1] : cur[NT - 1];
           if (CHAIN) {
             if (own0) cMx = Mp1[t];
-            if (own1) cO1 = Mp2[t];
+            if (CH >= 3 && own1) cO1 = Mp2[CH >= 3 ? t : 0];
           }
           V nI1{}, nD1{}, nI2{}, nD2{};
           int32_t m[VEC];
@@ -1446,7 +1453,11 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
               }
             }
             if (lane_on) st(row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t), voff, mv);
-            if (CHAIN) Mnew[t] = mv;
+            if constexpr (CHAIN && W16) Mnew[t] = mv;
+            if constexpr (CHAIN && !W16) {  // in place: this step has read its entries already (the registers of a second copy are not there)
+              if (CH >= 3) Mp2[CH >= 3 ? t : 0] = Mp1[t];
+              Mp1[t] = mv;
+            }
           }
           if (BASE && mp.end_comp == C_M) {
             const int je = mp.end_col - c0;
@@ -1473,7 +1484,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           }
         }
       }
-      if (CHAIN) {
+      if constexpr (CHAIN && W16) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) { Mp2[t] = Mp1[t]; Mp1[t] = Mnew[t]; }
       }
@@ -1598,7 +1609,7 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
   int nsteps = 0, npass = 0, why = MP_MARGIN;
   unsigned long long cells = 0;
   unsigned ext_iters = 0;
-  const int chain_cap = CHAIN ? min(max(uni(pc.chain_max), 1), CHAIN_MAX) : 1;
+  const int chain_cap = CHAIN ? min(max(uni(pc.chain_max), 1), sizeof(OffT) == 2 ? CHAIN_MAX : CHAIN_MAX32) : 1;
   for (;;) {
     // Start keeping every I/D row well before the furthest points can meet: the margin is several times what
     // the two searches advance while `scope` more rows (and one more pass) are computed.  The longest chain
@@ -2489,7 +2500,7 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
         // ---- the far-apart phase: all multi-step passes of this search in one call (multi_phase)
         if constexpr (MULTI_BUILD) {
           // (chained sweeps only where the scores allow them: 2-piece with x = TMAX and o1 + e1 = 2 TMAX, the default set)
-          if (P2) multi_phase<P2, OffT, 2, 1, P2 && sizeof(OffT) == 2>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
+          if (P2) multi_phase<P2, OffT, 2, 1, P2>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
           else if (pn.e1 == 1) multi_phase<P2, OffT, 1, 1, false>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
           else multi_phase<P2, OffT, 2, 1, false>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
         }

@@ -588,9 +588,9 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       kp.npairs = m;
       kp.pen = dp;
       kp.ring = ring;
-      // 32-bit rows: sweeps of at most TMAX32 scores (a lane vector is four registers), never chained
+      // 32-bit rows: sweeps of at most TMAX32 scores, at most CHAIN_MAX32 of them chained (a lane vector is four registers)
       kp.multi_T = narrow ? multi_T : (std::min(multi_T, awv::TMAX32) >= 2 ? std::min(multi_T, awv::TMAX32) : 0);
-      kp.chain_max = narrow ? chain_max : 1;
+      kp.chain_max = narrow ? chain_max : (awv::TMAX32 == awv::TMAX ? std::min(chain_max, awv::CHAIN_MAX32) : 1);
       kp.wcap = wc;
       kp.ring_mem = e->ring_mem.p;
       kp.ring_slot_stride = ring_stride;
