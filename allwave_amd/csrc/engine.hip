@@ -706,11 +706,38 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       const bool use_sixteen = !never_wide && !(e->cfg.flags & AWV_F_FOUR_WAVES) && n_huge > 0 && n_huge <= (int64_t)e->num_cus;
       const bool force32 = (e->cfg.flags & AWV_F_FORCE_INT32) != 0;
       const bool no_wide16 = (e->cfg.flags & AWV_F_NO_WIDE16) != 0;
+      std::vector<uint8_t> fl((size_t)n);
+      int64_t n_one = 0, n_four = 0;
       for (int64_t i = 0; i < n; ++i) {
         const int ql = s.len[hq[(size_t)i]], tl = s.len[ht[(size_t)i]];
         const int dl = std::abs(ql - tl);
         int f = (all_wide || (!never_wide && (dl >= 4096 || std::max(ql, tl) >= 32760))) ? 1 : 0;
         if (use_sixteen && dl >= 16384) f = 2;  // a forced gap that long: rows hundreds of windows wide
+        fl[(size_t)i] = (uint8_t)f;
+        n_one += f == 0;
+        n_four += f == 1;
+      }
+      // One-wave pairs that cannot fill the machine even once, next to pairs that go four waves anyway, are bound by their
+      // most expensive pair on a single wave while most of the machine idles: when their costs are uneven they go four
+      // waves too (config 5: 3,315 such pairs, 2.9 s at 61 % of the CUs busy).  (Pairs come in descending cost order.)
+      if (!never_wide && n_one > 0 && n_four > 0 && n_one <= (int64_t)(WAVES_PER_SIMD * 256 / AWV_THRU_WG) * e->num_cus) {
+        auto cost_of = [&](int64_t i) {
+          const int64_t ql = s.len[hq[(size_t)i]], tl = s.len[ht[(size_t)i]];
+          return (uint64_t)(ql + tl + 4 * std::llabs(ql - tl));
+        };
+        int64_t first_one = -1, seen = 0, median_one = -1;
+        for (int64_t i = 0; i < n && median_one < 0; ++i) {
+          if (fl[(size_t)i] != 0) continue;
+          if (first_one < 0) first_one = i;
+          if (seen++ == n_one / 2) median_one = i;
+        }
+        if (2 * cost_of(first_one) >= 3 * cost_of(median_one))  // (work grows with the square of this length measure: 1.5 x = more than twice the work)
+          for (int64_t i = 0; i < n; ++i)
+            if (fl[(size_t)i] == 0) fl[(size_t)i] = 1;
+      }
+      for (int64_t i = 0; i < n; ++i) {
+        const int ql = s.len[hq[(size_t)i]], tl = s.len[ht[(size_t)i]];
+        const int f = fl[(size_t)i];
         // row width: every stored value must fit 16 bits -- text offsets (both lengths short), or min(h, v) when only
         // the shorter sequence is (the kernels for that exist in the four- and sixteen-wave flavours)
         int w = force32 || std::max(ql, tl) >= 32760 ? 1 : 0;
