@@ -24,7 +24,7 @@ rows, 7 elements for 1-piece, + CIGAR bytes) over the kerne
 duration, against 8 TB/s HBM3E.  `cpu_baseline` is the CPU restatement (oracle/, kind "port") on a
 bounded sample of the same pairs on this box's host cores, at all cores and at one.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c1] [--pairs P]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c1|c4|c5] [--pairs P]
 """
 import argparse
 import json
@@ -88,8 +88,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default=None, choices=["c1", "c2", "c3"],
-                    help="default: c2 at N = 1, c3 (same read set on every GPU, prefix of its pair list) at N > 1")
+    ap.add_argument("--config", default=None, choices=["c1", "c2", "c3", "c4", "c5"],
+                    help="default: c2 at N = 1, c3 (same read set on every GPU, prefix of its pair list) at N > 1; c4 / c5: BASELINE "
+                         "configs[3] / [4] at their real sizes, pair list from the planner's sparsifier (kernel figures only)")
     ap.add_argument("--pairs", type=int, default=0,
                     help="length of the pair-list prefix (whole job, before sharding); default: all of c1/c2, N x 65,280 of c3")
     ap.add_argument("--workgroups", type=int, default=0)
@@ -145,19 +146,29 @@ def main():
     cname = args.config or ("c2" if world == 1 else "c3")
     cfg = synth.CONFIGS[cname]
     scores = cfg["scores"]
-    if cname == "c3" or world == 1:
+    sparse = cfg.get("sparsify", "none") != "none"  # c4 / c5: the planner's pair list (iterator.rs:30-92), long / mixed lengths
+    if sparse:
+        args.no_paf = True  # (the end-to-end legs below plan `-p none`: a million 100-kbp pairs for config 4)
+    if cname == "c3" or world == 1 or sparse:
         # one read set, the same on every GPU; the job is a prefix of its pair list, sharded over the ranks
-        data, offs, _ = synth.generate(cfg["nseq"], cfg["length"], cfg["d"], cfg["seed"])
-        all_pairs = synth.all_pairs(cfg["nseq"])
+        kw = {"mixed_lengths": cfg["mixed_lengths"]} if "mixed_lengths" in cfg else {}
+        data, offs, ids = synth.generate(cfg["nseq"], cfg["length"], cfg["d"], cfg["seed"], **kw)
+        if sparse:
+            from allwave_amd import host as H
+            all_pairs = np.ascontiguousarray(np.asarray(H.plan_pairs(ids, [bytes(data[offs[i]:offs[i + 1]]) for i in range(cfg["nseq"])],
+                                                                     cfg["sparsify"]), dtype=np.int32).reshape(-1, 2))
+        else:
+            all_pairs = synth.all_pairs(cfg["nseq"])
         prefix = args.pairs if args.pairs > 0 else (min(len(all_pairs), world * PAIRS_PER_GPU) if cname == "c3" else len(all_pairs))
         job = all_pairs[:prefix]
         lens = (offs[1:] - offs[:-1]).astype(np.int64)
         pairs = D.shard_pairs(job, rank, world, lens=lens, scores=scores)
         # per-GPU work is fixed as N grows unless --pairs fixes the whole job (then the shards shrink with N)
         scaling = "strong" if (args.pairs > 0 and world > 1) else "weak"
-        what = "%s: %d x %d bp synthetic, %.0f%% divergence, -p none (%d pairs), scores %s; job = first %d pairs of that list, " \
+        what = "%s: %d x %s bp synthetic, %.0f%% divergence, -p %s (%d pairs), scores %s; job = first %d pairs of that list, " \
                "same read set on every GPU, cost-balanced shards (equal costs: rank r aligns pairs r, r+N, ...): %d pairs per GPU per step" \
-               % (cname, cfg["nseq"], cfg["length"], 100 * cfg["d"], len(all_pairs), ",".join(map(str, scores)), len(job), len(pairs))
+               % (cname, cfg["nseq"], ("%d-%d" % cfg["mixed_lengths"]) if "mixed_lengths" in cfg else str(cfg["length"]), 100 * cfg["d"],
+                  cfg.get("sparsify", "none"), len(all_pairs), ",".join(map(str, scores)), len(job), len(pairs))
     else:
         # c1 / c2 on several GPUs: every rank owns an independent config-sized read set (weak scaling)
         data, offs, _ = synth.generate(cfg["nseq"], cfg["length"], cfg["d"], cfg["seed"] + 1000 * rank)
@@ -208,7 +219,12 @@ def main():
     # algorithmic bytes per cell-step: every component row written once and each source row
     # read once -- 2-piece: 5 written + 7 read = 12 offsets, 1-piece: 3 + 4 = 7 -- at the row element
     # size the launch used (2 B when all lengths < 32760, else 4 B; SURVEY 8d quotes the 4-byte figure)
-    esz = 2 if cfg["length"] < 32000 else 4
+    # (a pair runs on 16-bit rows when its shorter sequence has fewer than 32760 bases -- for a longer partner in the
+    # four-/sixteen-wave flavours, which is where such pairs go -- and on 32-bit rows otherwise; mixed sets are quoted at the
+    # element size of the majority of their pairs)
+    plens = (offs[1:] - offs[:-1]).astype(np.int64)
+    n32 = int((np.minimum(plens[pairs[:, 0]], plens[pairs[:, 1]]) >= 32760).sum()) if len(pairs) else 0
+    esz = 4 if 2 * n32 > len(pairs) else 2
     bytes_per_cell = (12 if len(scores) == 6 else 7) * esz
     algo_bytes = cells * bytes_per_cell + cig_bytes  # (extend probes read the LDS-staged packed sequences)
     kern_s = kernel_ms * 1e-3
@@ -248,7 +264,7 @@ def main():
         "higher_is_better": True,
         "scaling": scaling,
         "vs_baseline": None,
-        "dtype": "int16" if cfg["length"] < 32000 else "int32",
+        "dtype": "int32" if esz == 4 else ("int16" if n32 == 0 else "int16 (%d of %d pairs on int32 rows)" % (n32, len(pairs))),
         "data": "synthetic",
         "config": {"workload": what,
                    "parallelism": "pairs sharded over %d GPU(s), no collective on the data path" % world},

@@ -263,6 +263,18 @@ def test_multi_step_passes_all_presets(oracle, scores):
     finally:
         e.close()
     assert (res_multi["penalty"] == res_single["penalty"]).all() and cig_multi == cig_single
+    # the same passes on 32-bit rows (five-score sweeps whose sources are loaded one step ahead; chains of two under the
+    # default scores), one wave and four waves per pair
+    for flags in (ffi.AWV_F_ONE_WAVE | ffi.AWV_F_FORCE_INT32, ffi.AWV_F_FOUR_WAVES | ffi.AWV_F_FORCE_INT32):
+        e = ffi.Engine(flags=flags)
+        try:
+            e.set_sequences(seqs)
+            res32, cig32 = e.align_pairs(scores, pairs)
+            st = e.stats()
+            assert st.multi_cell_steps > 0.3 * st.cell_steps
+        finally:
+            e.close()
+        assert (res32["status"] == 0).all() and (res32["penalty"] == res_multi["penalty"]).all() and cig32 == cig_multi, flags
 
 
 def test_long_sequences_use_32bit_rows(engine, oracle):
