@@ -22,9 +22,14 @@
 //     (find_breakpoint_fn) and the trimmed-hull search (trim_pass_fn) are real functions with register
 //     files of their own; their inputs travel through LDS (Shared::pctx).
 //
+//   * rows are 16-bit whenever every stored value fits: text offsets when both sequences are shorter than
+//     32760, min(h, v) per cell when only the shorter one is (AWV_WIDE16: 32-bit row metadata); 32-bit rows
+//     otherwise, in 5-score sweeps whose M sources are loaded one step ahead, two sweeps chained.
+//
 // The header is compiled once per workgroup size: AWV_WG = 64 (one wave per pair: the throughput
-// kernel) and AWV_WG = 256 (four waves share a pair's rows: small batches and very expensive pairs),
-// each into its own namespace AWV_NS.
+// kernel), AWV_WG = 256 (four waves share a pair's rows: small batches and very expensive pairs) and
+// AWV_WG = 1024 (sixteen waves: a few enormous pairs), the latter two also with AWV_WIDE16, each into its
+// own namespace AWV_NS.
 
 
 #include <hip/hip_runtime.h>
