@@ -2705,7 +2705,6 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
   void* hist = (char*)kp.hist_mem + (size_t)blockIdx.x * kp.hist_slot_stride;
   uint32_t* events = kp.ev_mem + (size_t)blockIdx.x * kp.ev_slot_stride;
   Task* const stack = reinterpret_cast<Task*>(events + kp.wcap);  // the DFS stack lives behind the events (HBM; touched once per sub-problem)
-  const rsrc_t ring_rs = make_rsrc(ring_mem, kp.ring_slot_stride);
   const rsrc_t hist_rs = make_rsrc(hist, kp.hist_slot_stride);
   lds.meta_log = reinterpret_cast<RowMeta*>((char*)hist + kp.hist_meta_offset);
   if (tid < STAT_N) lstats[tid] = 0;
