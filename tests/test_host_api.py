@@ -43,6 +43,32 @@ def test_cigar_string_and_rc(host):
     assert host.reverse_complement(b"ACGTNacgtx") == b"NACGTNACGT"
 
 
+def test_cigar_run_lengths_every_alignment(host):
+    """The run-length encoder scans eight op bytes at a time: runs that start, end and straddle every offset inside a
+    word, runs of 1 .. 40 and a few long ones, against a byte-by-byte restatement of alignment.rs:347-376."""
+    import random
+    sym = {ord("M"): "=", ord("X"): "X", ord("I"): "D", ord("D"): "I"}
+
+    def rle(ops):
+        out, i = [], 0
+        while i < len(ops):
+            j = i
+            while j < len(ops) and ops[j] == ops[i]:
+                j += 1
+            out.append("%d%s" % (j - i, sym.get(ops[i], "?")))
+            i = j
+        return "".join(out)
+
+    rng = random.Random(8)
+    for lead in range(0, 9):
+        for run in list(range(1, 41)) + [63, 64, 65, 1000, 12345]:
+            ops = b"X" * lead + b"M" * run + b"I" + b"D" * (run % 7) + b"M"
+            assert host.cigar_bytes_to_string(ops) == rle(ops), (lead, run)
+    for _ in range(200):
+        ops = b"".join(bytes([rng.choice(b"MMMMXID")]) * rng.choice([1, 1, 2, 3, 7, 8, 9, 15, 16, 17, 50]) for _ in range(rng.randint(1, 60)))
+        assert host.cigar_bytes_to_string(ops) == rle(ops)
+
+
 def test_validate_cigar(host):
     """validation_correct.rs:139-175 semantics via wfa.rs:105-176: I consumes the reference, D the query."""
     assert host.validate_cigar(b"MMMM", 4, 4) is None
