@@ -30,15 +30,37 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+HIP_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950"]
+# kernels_awv.hip (the one-wave-per-pair kernels) only: the instruction scheduler orders for instruction-level parallelism
+# rather than for register pressure -- those kernels are bound by VALU issue (config 2, same-box A/B of the whole library:
+# 1723-1730 ms against 1762-1780 ms; "max-memory-clause": 1790-1796 ms).  Not for engine.hip: there it spills a lane
+# vector inside a pass loop of the 16-bit min(h, v) kernels (scratch/spill_audit.py).
+HIP_FLAGS_AWV = HIP_FLAGS + ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+HIP_UNITS = (("engine.hip", HIP_FLAGS), ("kernels_awv.hip", HIP_FLAGS_AWV))
+
+
 def build_hip(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "biwfa_device.hpp")] + \
+    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "kernels_awv.hip", "kernels_awv.hpp", "biwfa_device.hpp")] + \
            [os.path.join(ROOT, "include", "allwave_hip.h")]
     if force or _newer(HIP_LIB, srcs):
-        cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", HIP_LIB, os.path.join(CSRC, "engine.hip")]
+        inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+        objs, procs = [], []
+        for unit, flags in HIP_UNITS:  # the two translation units compile side by side
+            obj = os.path.join(CSRC, unit.replace(".hip", ".o"))
+            cmd = [hipcc()] + flags + ["-fPIC", "-c"] + inc + ["-o", obj, os.path.join(CSRC, unit)]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+            objs.append(obj)
+        for cmd, p in procs:
+            if p.wait() != 0:
+                raise subprocess.CalledProcessError(p.returncode, cmd)
+        cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", HIP_LIB] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        for obj in objs:
+            os.remove(obj)
     return HIP_LIB
 
 

@@ -7,9 +7,7 @@
 #include "allwave_hip.h"
 // the device code, once per workgroup size: awv:: one wave per pair (throughput), awvw:: four waves per pair,
 // awvx:: sixteen waves per pair (one pair per CU: the few pairs a large length difference makes enormous)
-#ifndef AWV_THRU_WG
-#define AWV_THRU_WG 64  // 128: two waves per pair, one per search direction (AWV_DIRSPLIT)
-#endif
+#include "kernels_awv.hpp"  // (AWV_THRU_WG; the awv:: kernels themselves are instantiated in kernels_awv.hip -- here only the types)
 #define AWV_NS awv
 #define AWV_WG AWV_THRU_WG
 #if AWV_THRU_WG == 128
@@ -618,8 +616,8 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       static_assert(sizeof(awvw::KParams) == sizeof(awv::KParams) && sizeof(awvx::KParams) == sizeof(awv::KParams),
                     "same parameter block for every workgroup size");
       if (waves == 1) {
-        if (dp.two_piece) lrc = narrow ? launch(awv::biwfa_align_kernel<true, int16_t>, kp) : launch(awv::biwfa_align_kernel<true, int32_t>, kp);
-        else lrc = narrow ? launch(awv::biwfa_align_kernel<false, int16_t>, kp) : launch(awv::biwfa_align_kernel<false, int32_t>, kp);
+        HIP_TRY((hipError_t)awv_launch_one_wave(dp.two_piece, narrow ? 1 : 0, (unsigned)nslots, dyn_lds, e->stream, &kp));
+        lrc = AWV_OK;
       } else if (wide_meta) {
         static_assert(sizeof(awvw_m::KParams) == sizeof(awv::KParams) && sizeof(awvx_m::KParams) == sizeof(awv::KParams), "same parameter block");
         if (waves == 4) {

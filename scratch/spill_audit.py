@@ -4,11 +4,14 @@ to device assembly and lists, per multi_phase / base_phase instantiation, the `F
 lie away from the function's prologue and epilogue.   usage: python scratch/spill_audit.py"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = os.path.join(tempfile.gettempdir(), "awv_engine_dev.s")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
-                       "-I" + os.path.join(ROOT, "allwave_amd", "csrc"), "-S", "--cuda-device-only",
-                       os.path.join(ROOT, "allwave_amd", "csrc", "engine.hip"), "-o", out], stderr=subprocess.DEVNULL)
-lines = open(out).read().split("\n")
+sys.path.insert(0, ROOT)
+from allwave_amd import build as B
+lines = []
+for unit, flags in B.HIP_UNITS:  # every translation unit with the options the library is built with
+    out = os.path.join(tempfile.gettempdir(), "awv_" + unit + ".s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "allwave_amd", "csrc"),
+                           "-S", "--cuda-device-only", os.path.join(ROOT, "allwave_amd", "csrc", unit), "-o", out], stderr=subprocess.DEVNULL)
+    lines += open(out).read().split("\n")
 funcs = [(i, m.group(1)) for i, l in enumerate(lines) for m in [re.match(r"^(_Z\w+):\s", l)] if m] + [(len(lines), "END")]
 worst = 0
 for (a, name), (b, _) in zip(funcs, funcs[1:]):
