@@ -33,7 +33,8 @@ def hipcc():
 HIP_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950"]
 # kernels_awv.hip (the one-wave-per-pair kernels) only: the instruction scheduler orders for instruction-level parallelism
 # rather than for register pressure -- those kernels are bound by VALU issue (config 2, same-box A/B of the whole library:
-# 1723-1730 ms against 1762-1780 ms; "max-memory-clause": 1790-1796 ms).  Not for engine.hip: there it spills a lane
+# 1723-1730 ms against 1762-1780 ms; "max-memory-clause": 1790-1796 ms; for this unit alone "iterative-ilp": 1845 ms,
+# "iterative-maxocc": 1779-1785 ms against 1719-1737 ms).  Not for engine.hip: there it spills a lane
 # vector inside a pass loop of the 16-bit min(h, v) kernels (scratch/spill_audit.py).
 HIP_FLAGS_AWV = HIP_FLAGS + ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 HIP_UNITS = (("engine.hip", HIP_FLAGS), ("kernels_awv.hip", HIP_FLAGS_AWV))
