@@ -100,7 +100,13 @@ enum { STAT_CELLS = 0, STAT_EXTEND, STAT_BREAKPOINTS, STAT_BASE, STAT_OVERLAP, S
        // cycle stamps (s_memtime, wave 0) -- only filled by the -DAWV_PROF diagnostic build
        STAT_T_TOTAL, STAT_T_BI_COMPUTE, STAT_T_BI_BARRIER, STAT_T_BI_FINALIZE, STAT_T_OVERLAP, STAT_T_BASE_STEPS,
        STAT_T_BACKTRACE, STAT_T_EMIT, STAT_N_PASSES,
-       STAT_T_CR_LOAD, STAT_T_CR_ALU, STAT_T_CR_EXTEND, STAT_T_CR_STORE, STAT_T_CR_REDUCE, STAT_RESTARTS, STAT_MULTI_CELLS, STAT_WIN_SINGLE, STAT_WIN_MULTI, STAT_WIN_BASE, STAT_WIN_BASE_MULTI, STAT_N };
+       STAT_T_CR_LOAD, STAT_T_CR_ALU, STAT_T_CR_EXTEND, STAT_T_CR_STORE, STAT_T_CR_REDUCE, STAT_RESTARTS, STAT_MULTI_CELLS, STAT_WIN_SINGLE, STAT_WIN_MULTI, STAT_WIN_BASE, STAT_WIN_BASE_MULTI,
+       // the shader clock the launch actually ran at: every persistent workgroup stamps s_memtime (shader cycles) and
+       // s_memrealtime (constant 100 MHz) once when it starts and once when it has drained the queue; the sums give
+       // cycles / ticks x 100 MHz (MI355X_MICROARCH.md: the clock under load is not the nominal 2.4 GHz)
+       STAT_CLK_CYCLES, STAT_CLK_TICKS,
+       STAT_DEEP_CELLS,  // cells computed by deep_phase (passes that also store every I/D row); part of STAT_MULTI_CELLS
+       STAT_N };
 
 #ifdef AWV_PROF
 #define PROF_DRAIN() __builtin_amdgcn_s_waitcnt(0)
@@ -131,6 +137,7 @@ struct KParams {
   int ring;        // power of two >= scope + 2 (+ multi_T - 1 with multi-step passes)
   int chain_max;   // sweeps a multi-step pass may chain (1: none; > 1 needs x == TMAX and o1 + e1 == 2 TMAX, ring >= scope + 2 + TMAX * chain_max - 1)
   int multi_T;     // steps per multi-step pass (0: off): <= min(TMAX, x, o1+e1, o2+e2, ring - scope - 1), e1/e2 among the instantiated depths
+  int deep_passes; // 1: the margin zone of phase 1 runs in passes that store every I/D row (deep_phase); 0: step by step there (round 2)
   int wcap;        // columns per ring row
   void* ring_mem;
   size_t ring_slot_stride;  // bytes per workgroup slot
@@ -207,8 +214,9 @@ struct PassCtx {
   // the breakpoint search as a function (find_breakpoint_fn): launch constants and the staged-sequence bookkeeping of the sub-problem
   unsigned long long Pw, Tw;
   int multi_T, lds_seq_bytes, pb_abs, tb_abs;
+  int deep_passes;
 };
-struct PhaseResult { int why, sc, fmax, rmax, npass; unsigned long long cells; };
+struct PhaseResult { int why, sc, fmax, rmax, npass; unsigned long long cells; int sf, sr, last_fwd; };  // sf / sr / last_fwd: deep_phase (official scores where phase 1 ended)
 struct Shared {
   Acc acc[3][2];
   int chain_maxak[2][16];  // multi_phase: per direction and step of the running pass, the row's max antidiagonal
@@ -218,7 +226,9 @@ struct Shared {
   unsigned long long ext_multi;  // extend probes counted by multi-step passes
   unsigned int win_single, win_multi, win_base, win_base_multi;  // windows processed (diagnostics)
   int ext0[2];
-  unsigned long long prof[5];
+#ifdef AWV_PROF
+  unsigned long long prof[5];  // (cycle stamps inside the step code: the -DAWV_PROF diagnostic build only; the static LDS reserve has no room to spare)
+#endif
   long long cur_pair;
   int error;
   int nev;
@@ -1116,10 +1126,14 @@ __device__ __forceinline__ void plan_multi(const KParams& kp, const Lds<OffT>& l
 // BASE: the base case's plain WFA (rows indexed by score in the history arena; every step also stores its I/D
 // rows -- the backtrace reads them -- and tells whether the end cell has been reached).
 // CHAIN: the pass may consist of several sweeps per window (mp.nh > 1); needs TMAX == x and 2 TMAX == o1 + e1.
-template <bool P2, typename OffT, int E1, int E2, bool BASE, bool CHAIN>
+// DEEPP: a pass of the breakpoint search that keeps everything the overlap search will read (deep_phase): every step's I/D
+// rows go to memory as well, and the rows' max antidiagonals are reported per step (maxak_out[t]) -- exactly what the
+// step-by-step loop leaves behind, at a pass's price.
+template <bool P2, typename OffT, int E1, int E2, bool BASE, bool CHAIN, bool DEEPP = false>
 __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh, const Lds<OffT>& lds, const SubCtx& cx, rsrc_t rs,
                                                   int dir, int s0, const MultiPlan& mp, Acc& acc, int* maxak_out, unsigned& ext_iters) {
-  constexpr bool DEEP = BASE;  // every step's I/D rows go to memory
+  constexpr bool DEEP = BASE || DEEPP;  // every step's I/D rows go to memory
+  static_assert(!(DEEPP && (BASE || CHAIN)), "deep passes of the search are single sweeps over the ring");
   constexpr bool W16 = sizeof(OffT) == 2;  // 16-bit rows: packed arithmetic; 32-bit rows: the same recurrences on 32-bit registers
   static_assert(E1 >= 1 && E1 <= 2 && E2 >= 1 && E2 <= 2, "register-resident I/D depth");
   static_assert(!(BASE && CHAIN), "the base case runs single sweeps");
@@ -1149,6 +1163,9 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
   const bool productive = lane >= halo && lane < 64 - halo;
   bool lane_oob = false;
   int lane_maxak = 0;       // max antidiagonal over all of the pass's productive cells
+  int lane_maxak_t[DEEPP ? TM : 1];  // DEEPP: per step
+#pragma unroll
+  for (int t = 0; t < (DEEPP ? TM : 1); ++t) lane_maxak_t[t] = 0;
   unsigned reach_mask = 0;  // BASE: bit t = the end cell has been reached at step t (uniform)
   typedef short s2 __attribute__((ext_vector_type(2)));
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -1453,8 +1470,9 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
               // the step's hull are NULL, and the halo lanes' sums are dropped at the end.
 #pragma unroll
               for (int j = 0; j < VEC; ++j) {
-                if constexpr (WE) lane_maxak = max(lane_maxak, 2 * m[j] + abs(k0 + j));  // h + v = 2 w + |k| (a NULL is OFF_NULL in m: far below 0; |k| may exceed 16384, so not from the clamped value)
-                else lane_maxak = max(lane_maxak, (c[j] - (k0 + j)) + c[j]);
+                int& mk = DEEPP ? lane_maxak_t[DEEPP ? t : 0] : lane_maxak;
+                if constexpr (WE) mk = max(mk, 2 * m[j] + abs(k0 + j));  // h + v = 2 w + |k| (a NULL is OFF_NULL in m: far below 0; |k| may exceed 16384, so not from the clamped value)
+                else mk = max(mk, (c[j] - (k0 + j)) + c[j]);
               }
             }
             if (lane_on) st(row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t), voff, mv);
@@ -1530,8 +1548,16 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
   }
   if (lane == 0 && woob) acc.oob = 1;
   if (!BASE) {
-    const int wmax = wave_max_i32(productive ? lane_maxak : 0);
-    if (lane == 0) atomicMax(&maxak_out[0], wmax);
+    if constexpr (DEEPP) {
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int wmax = wave_max_i32(productive ? lane_maxak_t[t] : 0);
+        if (lane == 0 && t < Tn) atomicMax(&maxak_out[t], wmax);
+      }
+    } else {
+      const int wmax = wave_max_i32(productive ? lane_maxak : 0);
+      if (lane == 0) atomicMax(&maxak_out[0], wmax);
+    }
   }
   if (BASE && lane == 0 && reach_mask) atomicOr(&acc.reach, (int)reach_mask);
   return cells;
@@ -1685,6 +1711,138 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
     pr.cells = cells;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { acc_reset(sh.acc[i][0]); acc_reset(sh.acc[i][1]); }  // whatever the caller's pass counter says next, its slot is clean
+  }
+  if (threadIdx.x < 32) sh.chain_maxak[threadIdx.x >> 4][threadIdx.x & 15] = 0;
+  atomicAdd(&sh.ext_multi, (unsigned long long)ext_iters);
+  __syncthreads();
+}
+
+// The rest of phase 1 in passes (round 3).  From the safety margin on, every I/D row has to be in memory -- the overlap search
+// of phase 2 reads those of the last `scope` scores -- and round 2 went step by step there: 80 % of all step-by-step window-steps
+// of config 2 lay in that zone (profiles/r03/zones.json).  deep_phase runs it in single sweeps of T scores that keep the I/D
+// queues in registers like any pass AND store every step's I/D rows (compute_rows_multi<DEEPP>), with the rows' max
+// antidiagonals per score, and replays WFA2's phase-1 bookkeeping (forward, test, reverse, test -- A.6) over the pass's scores
+// afterwards, exactly as the step-by-step loop would have run it.  The pass in which the furthest points can meet ends the
+// phase (MP_DEEP_MET): pres.sf / pres.sr are the official scores at that test, pres.last_fwd which side advanced last, and
+// pres.sc the score both directions are COMPUTED through -- the rows beyond the official scores are the ones phase 2 asks for
+// next, already there (nothing reads a row above the official scores, so computing them early changes no result; the ring
+// holds scope + T + 1 rows).  A pass in which a value leaves the matrix is discarded as in multi_phase (MP_DISCARD).
+constexpr int MP_DEEP_MET = 4;
+template <bool P2, typename OffT, int E1, int E2>
+__device__ __attribute__((noinline)) void deep_phase(unsigned sh_addr, unsigned dyn_addr, int s0_v, int fmax_v, int rmax_v, int Tn_v, int pass_v) {
+  Shared& sh = *(Shared*)__builtin_assume_aligned((Shared*)(lds_shared_ptr)(uintptr_t)uni((int)sh_addr), 8);
+  unsigned char* dyn_smem = (unsigned char*)__builtin_assume_aligned((unsigned char*)(lds_bytes_ptr)(uintptr_t)uni((int)dyn_addr), 16);
+  const int Tn = uni(Tn_v);
+  int sc = uni(s0_v);  // both directions stand at the same score when the phase begins and after every pass
+  int fmax = uni(fmax_v), rmax = uni(rmax_v), pass = uni(pass_v);
+  const PassCtx& pc = sh.pctx;
+  KParams kp{};
+  kp.ring = uni(pc.ring);
+  kp.wcap = uni(pc.wcap);
+  kp.pen.x = uni(pc.x);
+  kp.pen.o1 = uni(pc.o1);
+  kp.pen.e1 = uni(pc.e1);
+  kp.pen.o2 = uni(pc.o2);
+  kp.pen.e2 = uni(pc.e2);
+  kp.pen.two_piece = P2 ? 1 : 0;
+  kp.pen.scope = max(kp.pen.x, max(kp.pen.o1 + kp.pen.e1, P2 ? kp.pen.o2 + kp.pen.e2 : 0)) + 1;
+  kp.lds_meta_bytes = uni(pc.lds_meta_bytes);
+  auto uni64 = [](unsigned long long v) { return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)v); };
+  SubCtx cx;
+  cx.plen = uni(pc.plen);
+  cx.tlen = uni(pc.tlen);
+  cx.kmin[0] = uni(pc.kmin[0]);
+  cx.kmin[1] = uni(pc.kmin[1]);
+  cx.wcols = uni(pc.wcols);
+  cx.seq_mode = uni(pc.seq_mode);
+  cx.p_w0 = uni(pc.p_w0);
+  cx.t_w0 = uni(pc.t_w0);
+  cx.p_bit = uni(pc.p_bit);
+  cx.t_bit = uni(pc.t_bit);
+  cx.P[0] = (gseq_t)(uintptr_t)uni64(pc.P[0]);
+  cx.P[1] = (gseq_t)(uintptr_t)uni64(pc.P[1]);
+  cx.T[0] = (gseq_t)(uintptr_t)uni64(pc.T[0]);
+  cx.T[1] = (gseq_t)(uintptr_t)uni64(pc.T[1]);
+  cx.Pw = nullptr;
+  cx.Tw = nullptr;
+  cx.pb_abs = cx.tb_abs = 0;
+  Lds<OffT> lds;
+  typedef typename MetaTraits<OffT>::Stored MetaStored;
+  lds.ring_meta = reinterpret_cast<MetaStored*>(dyn_smem);
+  lds.bi_A = reinterpret_cast<int*>(lds.ring_meta + 2 * NCOMP * kp.ring);
+  lds.bi_oob = lds.bi_A + 2 * kp.ring;
+  lds.firstk = lds.bi_oob + 2 * kp.ring;
+  lds.seq = reinterpret_cast<uint32_t*>(dyn_smem + kp.lds_meta_bytes);
+  lds.meta_log = nullptr;
+  const rsrc_t rs = make_rsrc((void*)(uintptr_t)uni64(pc.ring_mem), (size_t)uni64(pc.ring_bytes));
+  const int rmask = kp.ring - 1;
+  const int max_antidiagonal = cx.plen + cx.tlen - 1;
+  int sf = sc, sr = sc, last_fwd = 0;  // official scores and the side that advanced last (WFA2's phase-1 loop, A.6)
+  int npass = 0, why = MP_DISCARD;
+  unsigned long long cells = 0;
+  unsigned ext_iters = 0;
+  for (;;) {
+    const int aslot = pass % 3;
+    int nc0 = 0, nc1 = 0;
+#pragma nounroll
+    for (int dir = 0; dir < 2; ++dir) {  // (one copy of the pass code, as in multi_phase)
+      MultiPlan mp;
+      plan_multi<P2, OffT, E1, E2, false>(kp, lds, cx, dir, sc, Tn, 1, mp);
+      Acc& acc = dir ? sh.acc[aslot][1] : sh.acc[aslot][0];
+      const int nc = compute_rows_multi<P2, OffT, E1, E2, false, false, true>(kp, sh, lds, cx, rs, dir, sc, mp, acc, dir ? sh.chain_maxak[1] : sh.chain_maxak[0], ext_iters);
+      if (dir) nc1 = nc; else nc0 = nc;
+    }
+    __syncthreads();
+    if (uni(sh.error)) { why = MP_ERROR; break; }
+    if (uni(sh.acc[aslot][0].oob) != 0 || uni(sh.acc[aslot][1].oob) != 0) { why = MP_DISCARD; break; }  // the pass assumed untrimmed rows: redone step by step
+    cells += (unsigned long long)(nc0 + nc1);
+    // The pass's rows become available: exact per-score maxima (what finalize_row records after a step), no out-of-bounds value.
+    // Then WFA2's phase-1 order over the pass's scores: forward, test, reverse, test -- the first test that holds ends phase 1
+    // right there (every thread computes the same from the same LDS values).
+    bool met = false;
+    for (int t = 0; t < Tn; ++t) {
+      const int slot = (sc + 1 + t) & rmask;
+      const int A0 = uni(sh.chain_maxak[0][t]), A1 = uni(sh.chain_maxak[1][t]);
+      lds.bi_A[slot] = A0;
+      lds.bi_A[kp.ring + slot] = A1;
+      lds.bi_oob[slot] = 0;
+      lds.bi_oob[kp.ring + slot] = 0;
+      if (!met) {
+        ++sf;
+        fmax = max(fmax, A0);
+        last_fwd = 1;
+        if (fmax + rmax >= max_antidiagonal) met = true;
+        else {
+          ++sr;
+          rmax = max(rmax, A1);
+          last_fwd = 0;
+          if (fmax + rmax >= max_antidiagonal) met = true;
+        }
+      }
+    }
+    __syncthreads();  // everyone has read the pass's maxima
+    if (threadIdx.x < 32) sh.chain_maxak[threadIdx.x >> 4][threadIdx.x & 15] = 0;
+    if (threadIdx.x == 0) { acc_reset(sh.acc[(pass + 2) % 3][0]); acc_reset(sh.acc[(pass + 2) % 3][1]); }
+    __syncthreads();  // ... and they are clear before the next pass adds to them
+    ++pass;
+    ++npass;
+    sc += Tn;
+    if (met) { why = MP_DEEP_MET; break; }
+  }
+  __syncthreads();  // every thread is past its last look at the accumulators
+  if (threadIdx.x == 0) {
+    PhaseResult& pr = sh.pres;
+    pr.why = why;
+    pr.sc = sc;
+    pr.sf = sf;
+    pr.sr = sr;
+    pr.last_fwd = last_fwd;
+    pr.fmax = fmax;
+    pr.rmax = rmax;
+    pr.npass = npass;
+    pr.cells = cells;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { acc_reset(sh.acc[i][0]); acc_reset(sh.acc[i][1]); }
   }
   if (threadIdx.x < 32) sh.chain_maxak[threadIdx.x >> 4][threadIdx.x & 15] = 0;
   atomicAdd(&sh.ext_multi, (unsigned long long)ext_iters);
@@ -2458,7 +2616,7 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
   int fmax = uni(lds.bi_A[(0) * kp.ring + (0)]), rmax = uni(lds.bi_A[(1) * kp.ring + (0)]);
   bp.score = INT_MAX;
   unsigned ext_iters = 0;
-  unsigned long long cells = 0, multi_cells = 0;
+  unsigned long long cells = 0, multi_cells = 0, deep_cells = 0;
   int pass = 0;
   const long long max_steps = ((long long)pn.o1 + pn.o2 + 2LL * (pn.e1 + pn.e2) + pn.x) * ((long long)plen + tlen + 4) + 1024;
   long long steps = 0;
@@ -2523,11 +2681,38 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
           cells += c;
           multi_cells += c;
         }
-        deep_on = true;  // from here on step by step: every row of every component goes to HBM
+        deep_on = true;  // from here on every row of every component goes to HBM
         deep_since[0] = comp[0] + 1;
         deep_since[1] = comp[1] + 1;
         last_fwd = false;
         __syncthreads();  // (sh.pres may be rewritten by the next search only after everyone has read it)
+        if (why == MP_MARGIN && kp.deep_passes) {
+          // ---- the rest of phase 1: passes that store every I/D row (deep_phase), until the furthest points can meet
+          const unsigned long long td0 = PROF_NOW();
+          if constexpr (MULTI_BUILD) {
+            if (P2) deep_phase<P2, OffT, 2, 1>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
+            else if (pn.e1 == 1) deep_phase<P2, OffT, 1, 1>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
+            else deep_phase<P2, OffT, 2, 1>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
+          }
+          PROF_ADD(STAT_T_BI_COMPUTE, td0);
+          const int dwhy = uni(sh.pres.why);
+          if (dwhy == MP_ERROR) { rc = uni(sh.error); break; }
+          steps += (long long)(uni(sh.pres.sc) - sc[0]);
+          comp[0] = comp[1] = uni(sh.pres.sc);  // computed through here; the official scores may stand below (rows phase 2 asks for next)
+          sc[0] = uni(sh.pres.sf);
+          sc[1] = uni(sh.pres.sr);
+          last_fwd = uni(sh.pres.last_fwd) != 0;
+          fmax = uni(sh.pres.fmax);
+          rmax = uni(sh.pres.rmax);
+          pass += uni(sh.pres.npass);
+          {
+            const unsigned long long c = ((unsigned long long)(unsigned)uni((int)(sh.pres.cells >> 32)) << 32) | (unsigned)uni((int)sh.pres.cells);
+            cells += c;
+            multi_cells += c;
+            deep_cells += c;
+          }
+          __syncthreads();
+        }
         continue;
       } else {
 #pragma unroll
@@ -2541,6 +2726,17 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
           phi[dir] = pl.hi;
         }
       }
+#ifdef AWV_DIAG
+      // diagnostic build: step-by-step window-steps by zone, reported through awv_stats.prof[9..13]
+      // ([9] sub-problems without passes, [10] before the passes can start, [11] margin zone of phase 1, [12] phase 2, [13] trimmed rows)
+      if (tid == 0) {
+        const int zone = (dirty[0] || dirty[1]) ? 4 : multi_T == 0 ? 0 : phase == 2 ? 3 : (sc[0] + 1 - (pn.scope - 1) >= 1) ? 2 : 1;
+        unsigned nw = 0;
+        if (need[0] && plo[0] <= phi[0]) nw += (unsigned)((phi[0] - plo[0] + 4) / 248 + 1);
+        if (need[1] && plo[1] <= phi[1]) nw += (unsigned)((phi[1] - plo[1] + 4) / 248 + 1);
+        lstats[STAT_T_CR_LOAD + zone] += nw;
+      }
+#endif
       if (need[0] || need[1]) {
         PROF_ADD(STAT_T_BI_COMPUTE, tp0);
         PROF_INC(STAT_N_PASSES);
@@ -2608,6 +2804,7 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
   } else if (tid == 0) {
     lstats[STAT_CELLS] += cells;
     lstats[STAT_MULTI_CELLS] += multi_cells;
+    lstats[STAT_DEEP_CELLS] += deep_cells;
     lstats[STAT_BREAKPOINTS] += 1;
   }
   atomicAdd(&lstats[STAT_EXTEND], (unsigned long long)ext_iters);
@@ -2646,6 +2843,7 @@ __device__ __attribute__((noinline)) int find_breakpoint_fn(unsigned sh_addr, un
   kp.lds_seq_bytes = uni(pc.lds_seq_bytes);
   kp.chain_max = uni(pc.chain_max);
   kp.multi_T = uni(pc.multi_T);
+  kp.deep_passes = uni(pc.deep_passes);
   kp.ring_slot_stride = (size_t)uni64(pc.ring_bytes);
   SubCtx cx;
   cx.plen = uni(pc.plen);
@@ -2708,7 +2906,10 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
   const rsrc_t hist_rs = make_rsrc(hist, kp.hist_slot_stride);
   lds.meta_log = reinterpret_cast<RowMeta*>((char*)hist + kp.hist_meta_offset);
   if (tid < STAT_N) lstats[tid] = 0;
+#ifdef AWV_PROF
   if (tid < 5) sh.prof[tid] = 0;
+#endif
+  const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
   if (tid < 32) sh.chain_maxak[tid >> 4][tid & 15] = 0;
   __syncthreads();
   for (;;) {
@@ -2805,6 +3006,7 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
             pc.lds_seq_bytes = kp.lds_seq_bytes;
             pc.chain_max = kp.chain_max;
             pc.multi_T = kp.multi_T;
+            pc.deep_passes = kp.deep_passes;
             pc.plen = plen; pc.tlen = tlen;
             pc.seq_mode = cx.seq_mode; pc.p_w0 = cx.p_w0; pc.t_w0 = cx.t_w0; pc.p_bit = cx.p_bit; pc.t_bit = cx.t_bit;
             pc.pb_abs = cx.pb_abs; pc.tb_abs = cx.tb_abs;
@@ -2867,7 +3069,13 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
     __syncthreads();
   }
   __syncthreads();
+  if (tid == 0) {
+    lstats[STAT_CLK_CYCLES] = __builtin_amdgcn_s_memtime() - clk_c0;
+    lstats[STAT_CLK_TICKS] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+  }
+#ifdef AWV_PROF
   if (tid < 5) lstats[STAT_T_CR_LOAD + tid] = sh.prof[tid];
+#endif
   __syncthreads();
   if (tid < STAT_N && lstats[tid]) atomicAdd(&kp.stats[tid], lstats[tid]);
 }

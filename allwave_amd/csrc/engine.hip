@@ -144,6 +144,7 @@ struct awv_engine {
   awv_engine_config cfg{};
   int device = 0;
   int num_cus = 0;
+  int wall_clock_khz = 100000;  // rate of s_memrealtime (hipDeviceAttributeWallClockRate)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   SeqSet seqs;
@@ -588,6 +589,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       kp.ring = ring;
       // 32-bit rows: sweeps of at most TMAX32 scores, at most CHAIN_MAX32 of them chained (a lane vector is four registers)
       kp.multi_T = narrow ? multi_T : (std::min(multi_T, awv::TMAX32) >= 2 ? std::min(multi_T, awv::TMAX32) : 0);
+      kp.deep_passes = (kp.multi_T > 0 && !(e->cfg.flags & AWV_F_NO_DEEP)) ? 1 : 0;
       kp.chain_max = narrow ? chain_max : (awv::TMAX32 == awv::TMAX ? std::min(chain_max, awv::CHAIN_MAX32) : 1);
       kp.wcap = wc;
       kp.ring_mem = e->ring_mem.p;
@@ -666,7 +668,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       for (int64_t i = 0; i < m; ++i) {
         const int64_t bi = amap.empty() ? i : amap[(size_t)i];
         hres[(size_t)bi] = tres[(size_t)i];
-        if (tres[(size_t)i].status == AWV_ST_CAPACITY && wc < wcap_full) again.push_back(i);
+        if (tres[(size_t)i].status == AWV_ST_CAPACITY && wc < wcap_full && !(e->cfg.flags & AWV_F_NO_RERUN)) again.push_back(i);
       }
       if (again.empty()) break;
       std::vector<int32_t> q2, t2, rc2;
@@ -827,6 +829,10 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
   e->stats.windows[1] = stat_tot[STAT_WIN_MULTI];
   e->stats.windows[2] = stat_tot[STAT_WIN_BASE];
   e->stats.windows[3] = stat_tot[STAT_WIN_BASE_MULTI];
+  e->stats.clock_cycles = stat_tot[STAT_CLK_CYCLES];
+  e->stats.clock_ticks = stat_tot[STAT_CLK_TICKS];
+  e->stats.clock_tick_khz = (uint64_t)e->wall_clock_khz;
+  e->stats.deep_cell_steps = stat_tot[STAT_DEEP_CELLS];
   return AWV_OK;
 }
 
@@ -863,6 +869,11 @@ int awv_engine_create(const awv_engine_config* cfg, awv_engine** out) {
   hipDeviceProp_t prop;
   if ((he = hipGetDeviceProperties(&prop, e->device)) != hipSuccess) return bail(he, "hipGetDeviceProperties");
   e->num_cus = prop.multiProcessorCount;
+  {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device) == hipSuccess && khz > 0) e->wall_clock_khz = khz;
+    else (void)hipGetLastError();
+  }
   if ((he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess) return bail(he, "hipStreamCreate");
   if ((he = hipEventCreate(&e->ev0)) != hipSuccess) return bail(he, "hipEventCreate");
   if ((he = hipEventCreate(&e->ev1)) != hipSuccess) return bail(he, "hipEventCreate");

@@ -200,26 +200,35 @@ namespace {
 // per-thread aligners, alignment.rs:11-22): its HBM arenas are tens of GB, and allocating them right
 // after a free can take the driver seconds.  A holder owns the device's engine for its lifetime.
 std::atomic<int> g_engine_flags{0};  // awv_engine_config.flags of engines created from now on (set_engine_flags)
+std::atomic<int> g_engine_first_row_cols{0};  // awv_engine_config.first_row_cols, likewise (diagnostic / test hook)
+struct EngineTable {
+  std::mutex mu;  // guards the table
+  std::map<int, std::pair<awv_engine*, std::unique_ptr<std::mutex>>> engines;
+};
+EngineTable& engine_table() {
+  static EngineTable t;
+  return t;
+}
 struct EngineHolder {
   awv_engine* e = nullptr;
   std::unique_lock<std::mutex> lock;
   explicit EngineHolder(int device) {
-    static std::mutex mu;                       // guards the table
-    static std::map<int, std::pair<awv_engine*, std::unique_ptr<std::mutex>>> engines;
+    EngineTable& tb = engine_table();
     std::mutex* dev_mu;
     {
-      std::lock_guard<std::mutex> g(mu);
-      auto& slot = engines[device];
+      std::lock_guard<std::mutex> g(tb.mu);
+      auto& slot = tb.engines[device];
       if (!slot.second) slot.second.reset(new std::mutex());
       dev_mu = slot.second.get();
     }
     lock = std::unique_lock<std::mutex>(*dev_mu);  // one run at a time per device
-    std::lock_guard<std::mutex> g(mu);
-    auto& slot = engines[device];
+    std::lock_guard<std::mutex> g(tb.mu);
+    auto& slot = tb.engines[device];
     if (!slot.first) {
       awv_engine_config cfg{};
       cfg.device = device;
       cfg.flags = g_engine_flags.load();
+      cfg.first_row_cols = g_engine_first_row_cols.load();
       if (awv_engine_create(&cfg, &slot.first) != AWV_OK) throw AlignmentError(std::string("engine: ") + awv_last_error());
     }
     e = slot.first;
@@ -298,6 +307,16 @@ AllPairIterator& AllPairIterator::with_orientation_params(AlignmentParams p) { o
 AllPairIterator& AllPairIterator::with_orientation(Orientation o) { orientation_ = o; return *this; }
 AllPairIterator& AllPairIterator::with_device(int device) { device_ = device; return *this; }
 void set_engine_flags(int flags) { g_engine_flags.store(flags); }
+void set_engine_first_row_cols(int cols) { g_engine_first_row_cols.store(cols); }
+void release_engines() {
+  EngineTable& tb = engine_table();
+  std::lock_guard<std::mutex> g(tb.mu);
+  for (auto& kv : tb.engines) {
+    std::lock_guard<std::mutex> busy(*kv.second.second);  // (waits for a run in flight on that device)
+    if (kv.second.first) awv_engine_destroy(kv.second.first);
+    kv.second.first = nullptr;
+  }
+}
 AllPairIterator& AllPairIterator::with_shard(size_t rank, size_t world) {
   // cost-balanced shards (planner::assign_shards_lpt): every process derives the same partition and
   // keeps its own part, in list order; equal-cost lists (config 2 / 3) come out strided
@@ -314,8 +333,87 @@ AllPairIterator& AllPairIterator::with_shard(size_t rank, size_t world) {
   return *this;
 }
 
-void AllPairIterator::run(const std::function<void(int64_t, int64_t, const awv_result*, const uint8_t*,
-                                                   const std::vector<uint8_t>&)>& batch_cb) {
+AllPairIterator AllPairIterator::with_sparsification(SparsificationStrategy strategy) const {  // iterator.rs:101-110
+  AllPairIterator it = with_options(sequences_, params_, exclude_self_, orientation_ == Orientation::Mash, std::move(strategy));
+  if (orientation_ == Orientation::ForwardOnly) it.orientation_ = Orientation::ForwardOnly;  // (this build's extension survives)
+  it.device_ = device_;
+  it.threads_ = threads_;
+  it.next_chunk_ = next_chunk_;
+  return it;
+}
+AllPairIterator& AllPairIterator::with_next_chunk(size_t n) { next_chunk_ = std::max<size_t>(1, n); return *this; }
+AllPairIterator& AllPairIterator::with_threads(int t) { threads_ = t; return *this; }
+AllPairParallelIterator AllPairIterator::into_par_iter() const { return AllPairParallelIterator(*this); }
+
+std::optional<AlignmentResult> AllPairIterator::next() {  // iterator.rs:151-171
+  if (next_buf_pos_ >= next_buf_.size()) {
+    next_buf_.clear();
+    next_buf_pos_ = 0;
+    if (next_pos_ >= pairs_.size()) return std::nullopt;
+    const size_t first = next_pos_, cnt = std::min(next_chunk_, pairs_.size() - first);
+    next_buf_.resize(cnt);
+    run_range(first, cnt, [&](int64_t bf, int64_t bn, const awv_result* res, const uint8_t* arena, const std::vector<uint8_t>& rev) {
+      for (int64_t i = 0; i < bn; ++i) {
+        const auto& pr = pairs_[first + (size_t)(bf + i)];
+        next_buf_[(size_t)(bf + i)] = make_result(pr.first, pr.second, rev[(size_t)(bf + i)] != 0, res[i], arena, true);
+      }
+    });
+    next_pos_ += cnt;
+  }
+  return std::move(next_buf_[next_buf_pos_++]);
+}
+
+void AllPairParallelIterator::for_each_with_callback(const Callback& cb) {
+  const int want = threads_ > 0 ? threads_ : (it_.threads_ > 0 ? it_.threads_ : planner::host_threads());
+  it_.run([&](int64_t first, int64_t cnt, const awv_result* res, const uint8_t* arena, const std::vector<uint8_t>& rev) {
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(want, cnt));
+    std::mutex mu;
+    std::exception_ptr err;  // the first error wins (iterator.rs:236-242); the other workers stop at their next pair
+    std::atomic<bool> stop{false};
+    std::atomic<int64_t> cursor{0};
+    auto work = [&]() {
+      for (;;) {
+        const int64_t i = cursor.fetch_add(1);
+        if (i >= cnt || stop.load()) return;
+        const auto& pr = it_.pairs_[(size_t)(first + i)];
+        try {
+          cb(make_result(pr.first, pr.second, rev[(size_t)(first + i)] != 0, res[i], arena, true));
+        } catch (...) {
+          std::lock_guard<std::mutex> g(mu);
+          if (!err) err = std::current_exception();
+          stop.store(true);
+          return;
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    if (err) std::rethrow_exception(err);
+  });
+}
+
+std::vector<AlignmentResult> AllPairParallelIterator::collect() {
+  std::vector<AlignmentResult> out(it_.pairs_.size());
+  it_.run([&](int64_t first, int64_t cnt, const awv_result* res, const uint8_t* arena, const std::vector<uint8_t>& rev) {
+    for (int64_t i = 0; i < cnt; ++i) {
+      const auto& pr = it_.pairs_[(size_t)(first + i)];
+      out[(size_t)(first + i)] = make_result(pr.first, pr.second, rev[(size_t)(first + i)] != 0, res[i], arena, true);
+    }
+  });
+  return out;
+}
+
+void process_alignments_with_callback(const std::vector<Sequence>& sequences, AlignmentParams params,
+                                      SparsificationStrategy sparsification, const Callback& callback) {  // lib.rs:57-68
+  AllPairIterator aligner = AllPairIterator::with_options(sequences, std::move(params), true, true, std::move(sparsification));
+  aligner.for_each_with_callback(callback);
+}
+
+void AllPairIterator::run_range(size_t range_first, size_t range_count,
+                                const std::function<void(int64_t, int64_t, const awv_result*, const uint8_t*,
+                                                         const std::vector<uint8_t>&)>& batch_cb) {
 #ifdef AWV_DEBUG_KNOBS
   const bool timing = getenv("AWH_TIMING") != nullptr;  // diagnostic: stage times on stderr
 #else
@@ -329,18 +427,25 @@ void AllPairIterator::run(const std::function<void(int64_t, int64_t, const awv_r
   lap("engine created");
   upload(eh.e, sequences_);
   lap("sequences uploaded");
-  const int64_t n = (int64_t)pairs_.size();
+  if (range_first > pairs_.size() || range_count > pairs_.size() - range_first) throw AlignmentError("pair range out of bounds");
+  // (a sub-range -- sequential next() -- works on its own copy of the slice; the whole list is used in place)
+  const bool whole = range_first == 0 && range_count == pairs_.size();
+  std::vector<std::pair<size_t, size_t>> slice;
+  if (!whole) slice.assign(pairs_.begin() + (ptrdiff_t)range_first, pairs_.begin() + (ptrdiff_t)(range_first + range_count));
+  const std::vector<std::pair<size_t, size_t>>& plist = whole ? pairs_ : slice;
+  const int64_t n = (int64_t)plist.size();
+  const int host_thr = threads_ > 0 ? threads_ : planner::host_threads();
   std::vector<uint8_t> is_rev((size_t)n, 0);
   std::vector<awv_pair> ap((size_t)n);
   if (orientation_ == Orientation::Mash) {
-    is_rev = planner::orient_pairs_mash(sequences_, pairs_, planner::host_threads());  // alignment.rs:69-94 (host threads: the CLI's -t)
+    is_rev = planner::orient_pairs_mash(sequences_, plist, host_thr);  // alignment.rs:69-94 (host threads: the CLI's -t)
   } else if (orientation_ == Orientation::Wfa) {
     // determine_orientation_wfa (alignment.rs:157-175): align forward and reverse-complement with the
     // orientation params, compare #X+#I+#D; forward wins ties; a failed alignment counts as usize::MAX
     std::vector<awv_pair> op((size_t)2 * n);
     for (int64_t i = 0; i < n; ++i) {
-      op[2 * i] = awv_pair{(int32_t)pairs_[i].first, (int32_t)pairs_[i].second, 0};
-      op[2 * i + 1] = awv_pair{(int32_t)pairs_[i].first, (int32_t)pairs_[i].second, 1};
+      op[2 * i] = awv_pair{(int32_t)plist[i].first, (int32_t)plist[i].second, 0};
+      op[2 * i + 1] = awv_pair{(int32_t)plist[i].first, (int32_t)plist[i].second, 1};
     }
     std::vector<awv_result> orr((size_t)2 * n);
     const awv_penalties open = to_penalties(orientation_params_);
@@ -353,7 +458,7 @@ void AllPairIterator::run(const std::function<void(int64_t, int64_t, const awv_r
       is_rev[i] = dist(orr[2 * i]) <= dist(orr[2 * i + 1]) ? 0 : 1;
     }
   }
-  for (int64_t i = 0; i < n; ++i) ap[i] = awv_pair{(int32_t)pairs_[i].first, (int32_t)pairs_[i].second, is_rev[i]};
+  for (int64_t i = 0; i < n; ++i) ap[i] = awv_pair{(int32_t)plist[i].first, (int32_t)plist[i].second, is_rev[i]};
   using BatchCb = std::function<void(int64_t, int64_t, const awv_result*, const uint8_t*, const std::vector<uint8_t>&)>;
   struct Ctx {
     const BatchCb* cb;

@@ -88,13 +88,32 @@ using Callback = std::function<void(AlignmentResult&&)>;  // may throw: first er
 // awv_engine_config.flags (AWV_F_*) for the per-device engines this library creates from now on
 // (an engine lives for the rest of the process once created).
 void set_engine_flags(int flags);
+void set_engine_first_row_cols(int cols);  // awv_engine_config.first_row_cols, likewise (diagnostic / test hook)
+// destroys the per-device engines this library holds (their HBM arenas are freed; the next run creates fresh ones with the
+// flags then in force)
+void release_engines();
 
-class AllPairIterator {  // iterator.rs:12-149
+class AllPairParallelIterator;
+
+class AllPairIterator {  // iterator.rs:12-171
  public:
   AllPairIterator(const std::vector<Sequence>& sequences, AlignmentParams params);  // ::new
   static AllPairIterator with_options(const std::vector<Sequence>& sequences, AlignmentParams params,
                                       bool exclude_self, bool use_mash_orientation, SparsificationStrategy s);
   AllPairIterator& with_orientation_params(AlignmentParams p);
+  // iterator.rs:101-110: a NEW iterator over the same sequences / params / exclude_self / orientation choice with the pair
+  // list planned again under `strategy` -- through with_options, exactly like the reference, so the orientation params go
+  // back to their default (edit_distance) there too; the device and thread settings (this build's extensions) carry over
+  AllPairIterator with_sparsification(SparsificationStrategy strategy) const;
+  // iterator.rs:113-125: the batch-parallel consumer (rayon's par_iter in the reference)
+  AllPairParallelIterator into_par_iter() const;
+  // iterator.rs:151-171 (`impl Iterator`): the next pair's alignment, in pair-list order; std::nullopt at the end.  A per-pair
+  // call cannot feed a GPU, so the results are buffered: an empty buffer aligns the next `next_chunk` pairs in one engine call.
+  std::optional<AlignmentResult> next();
+  AllPairIterator& with_next_chunk(size_t pairs_per_engine_call);
+  // host threads for sketching / orientation / formatting of THIS iterator's runs (the reference's `-t`; 0 = the
+  // process-wide planner::host_threads())
+  AllPairIterator& with_threads(int host_threads);
   AllPairIterator& with_orientation(Orientation o);
   AllPairIterator& with_device(int device);
   // keep pairs rank, rank + world, ... of the planned list (one process per GPU: every pair lands on
@@ -111,16 +130,48 @@ class AllPairIterator {  // iterator.rs:12-149
   awv_stats last_stats() const { return stats_; }
 
  private:
+  friend class AllPairParallelIterator;
   void run(const std::function<void(int64_t first, int64_t n, const awv_result* res, const uint8_t* arena,
-                                    const std::vector<uint8_t>& is_rev)>& batch_cb);
+                                    const std::vector<uint8_t>& is_rev)>& batch_cb) { run_range(0, pairs_.size(), batch_cb); }
+  // pairs_[first, first + count) through one orientation pass + one awv_align_pairs call; batch indices are relative to `first`
+  void run_range(size_t first, size_t count,
+                 const std::function<void(int64_t first, int64_t n, const awv_result* res, const uint8_t* arena,
+                                          const std::vector<uint8_t>& is_rev)>& batch_cb);
   const std::vector<Sequence>& sequences_;
   AlignmentParams params_, orientation_params_;
   bool exclude_self_ = true;
   Orientation orientation_ = Orientation::Wfa;
   int device_ = 0;
+  int threads_ = 0;
   std::vector<std::pair<size_t, size_t>> pairs_;
   awv_stats stats_{};
+  // sequential iteration (next): position in the pair list and the buffered results of the running chunk
+  size_t next_pos_ = 0, next_chunk_ = 16384;
+  std::vector<AlignmentResult> next_buf_;
+  size_t next_buf_pos_ = 0;
 };
+
+// iterator.rs:174-253.  The reference's parallel iterator maps align_pair over the pairs on rayon's workers and hands every
+// result to a consumer that runs on those workers concurrently; here the pairs go through the engine in batches and every
+// batch's results are handed to `callback` from `threads` host threads at once (same contract: the callback must be
+// thread-safe; the first error it throws wins, stops the run and is rethrown -- iterator.rs:220-251).
+class AllPairParallelIterator {
+ public:
+  size_t pair_count() const { return it_.pair_count(); }
+  AllPairParallelIterator& with_threads(int threads) { threads_ = threads; return *this; }
+  void for_each_with_callback(const Callback& cb);   // iterator.rs:206-253
+  std::vector<AlignmentResult> collect();           // rayon's collect() on the parallel iterator: results in pair-list order
+ private:
+  friend class AllPairIterator;
+  explicit AllPairParallelIterator(const AllPairIterator& it) : it_(it) {}
+  AllPairIterator it_;
+  int threads_ = 0;  // 0 = planner::host_threads()
+};
+
+// lib.rs:57-68: AllPairIterator::with_options(sequences, params, exclude_self = true, mash orientation = true, sparsification)
+// .for_each_with_callback(callback); the callback may throw (first error aborts and is rethrown)
+void process_alignments_with_callback(const std::vector<Sequence>& sequences, AlignmentParams params,
+                                      SparsificationStrategy sparsification, const Callback& callback);
 
 namespace wfa {  // src/wfa.rs
 struct Penalties { int32_t mismatch, gap_opening1, gap_extension1, gap_opening2, gap_extension2; };

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "allwave.hpp"
 #include "planner.hpp"
@@ -100,6 +101,55 @@ int awh_all_pairs_paf(int n, const char* const* ids, const uint8_t* bytes, const
   } catch (const std::exception& e) { set_err(err, cap, e.what()); return -1; }
 }
 
+// Every consumer of the pair list the reference offers, one per `mode` (tests/test_host_api.py):
+//   0  AllPairIterator::for_each_with_callback                 iterator.rs:127-137
+//   1  the sequential `impl Iterator` (next() until the end)    iterator.rs:151-171
+//   2  into_par_iter().for_each_with_callback on `threads`      iterator.rs:113-125,206-253
+//   3  into_par_iter().collect()                                iterator.rs:182-203 (rayon collect)
+//   4  process_alignments_with_callback                         lib.rs:57-68 (mash orientation, exclude_self)
+// `resparsify`: plan with -p none first, then call with_sparsification(strategy) (iterator.rs:101-110).
+// `fail_at` >= 0: the callback throws at its fail_at-th record; the call must fail with that message (first error wins).
+// out = PAF lines in the order the records arrived.
+int awh_iterate(int n, const char* const* ids, const uint8_t* bytes, const uint64_t* offs, const char* scores,
+                const char* sparsification, int orientation, int mode, int threads, int chunk, int resparsify, long fail_at,
+                int device, char** out, size_t* out_len, size_t* n_records, char* err, size_t cap) {
+  try {
+    const std::vector<Sequence> seqs = make_seqs(n, ids, bytes, offs);
+    const SparsificationStrategy strat = SparsificationStrategy::parse(sparsification ? sparsification : "none");
+    const Orientation orient = orientation == 0 ? Orientation::ForwardOnly : orientation == 1 ? Orientation::Wfa : Orientation::Mash;
+    std::mutex mu;
+    std::string all;
+    size_t seen = 0;
+    auto record = [&](AlignmentResult&& r) {
+      std::string line = alignment_to_paf(r, seqs);
+      std::lock_guard<std::mutex> g(mu);
+      if (fail_at >= 0 && (long)seen == fail_at) throw std::runtime_error("callback failed at record " + std::to_string(seen));
+      ++seen;
+      all += line;
+      all.push_back('\n');
+    };
+    if (mode == 4) {
+      process_alignments_with_callback(seqs, parse_scores(scores), strat, record);
+    } else {
+      AllPairIterator it0 = AllPairIterator::with_options(seqs, parse_scores(scores), true, orientation == 2,
+                                                         resparsify ? SparsificationStrategy{} : strat);
+      it0.with_orientation(orient).with_device(device);
+      if (chunk > 0) it0.with_next_chunk((size_t)chunk);
+      AllPairIterator it = resparsify ? it0.with_sparsification(strat) : it0;
+      if (mode == 0) it.for_each_with_callback(record);
+      else if (mode == 1) { while (auto r = it.next()) record(std::move(*r)); }
+      else if (mode == 2) it.into_par_iter().with_threads(threads).for_each_with_callback(record);
+      else if (mode == 3) { for (auto& r : it.into_par_iter().collect()) record(std::move(r)); }
+      else throw std::invalid_argument("awh_iterate: unknown mode");
+    }
+    *out = (char*)malloc(all.size() + 1);
+    memcpy(*out, all.c_str(), all.size() + 1);
+    *out_len = all.size();
+    *n_records = seen;
+    return 0;
+  } catch (const std::exception& e) { set_err(err, cap, e.what()); return -1; }
+}
+
 // End-to-end measurement: sequences -> GPU alignment -> D2H -> PAF text into a counting sink.
 int awh_all_pairs_paf_count(int n, const char* const* ids, const uint8_t* bytes, const uint64_t* offs, const char* scores,
                             int orientation, int device, int format_threads, uint64_t* out_bytes, uint64_t* out_lines,
@@ -108,7 +158,7 @@ int awh_all_pairs_paf_count(int n, const char* const* ids, const uint8_t* bytes,
     const std::vector<Sequence> seqs = make_seqs(n, ids, bytes, offs);
     AllPairIterator it(seqs, parse_scores(scores));
     it.with_orientation(orientation == 0 ? Orientation::ForwardOnly : orientation == 1 ? Orientation::Wfa : Orientation::Mash).with_device(device);
-    planner::set_host_threads(format_threads);
+    it.with_threads(format_threads);  // this call's sketching / orientation threads: carried by the iterator, not a process-wide setting
     uint64_t nb = 0, nl = 0;
     const auto t0 = std::chrono::steady_clock::now();
     it.for_each_paf_batch([&](const std::string& s) {
@@ -155,8 +205,11 @@ int awh_plan_pairs(int n, const char* const* ids, const uint8_t* bytes, const ui
                    int exclude_self, int64_t** out, size_t* npairs, char* err, size_t cap) {
   try {
     const std::vector<Sequence> seqs = make_seqs(n, ids, bytes, offs);
-    AllPairIterator it = AllPairIterator::with_options(seqs, AlignmentParams{}, exclude_self != 0, false,
-                                                      SparsificationStrategy::parse(sparsification));
+    // exclude_self & 2: plan with -p none first, then with_sparsification(strategy) (iterator.rs:101-110)
+    const bool resparsify = (exclude_self & 2) != 0;
+    AllPairIterator it0 = AllPairIterator::with_options(seqs, AlignmentParams{}, (exclude_self & 1) != 0, false,
+                                                       resparsify ? SparsificationStrategy{} : SparsificationStrategy::parse(sparsification));
+    AllPairIterator it = resparsify ? it0.with_sparsification(SparsificationStrategy::parse(sparsification)) : it0;
     const auto& p = it.get_pairs();
     *out = (int64_t*)malloc(sizeof(int64_t) * 2 * (p.size() + 1));
     for (size_t i = 0; i < p.size(); ++i) { (*out)[2 * i] = (int64_t)p[i].first; (*out)[2 * i + 1] = (int64_t)p[i].second; }
@@ -194,17 +247,30 @@ int awh_orient_mash(int n, const char* const* ids, const uint8_t* bytes, const u
 
 // shard of every pair under the cost-balanced (LPT) partition AllPairIterator::with_shard uses; cost_out (nullable)
 // receives the predicted costs
-int awh_shard_pairs(const int64_t* pairs, size_t npairs, const int64_t* lens, const char* scores, size_t world, uint32_t* shard_out,
+int awh_shard_pairs(const int64_t* pairs, size_t npairs, const int64_t* lens, size_t nseq, const char* scores, size_t world, uint32_t* shard_out,
                     double* cost_out, char* err, size_t cap) {
   try {
     const AlignmentParams p = parse_scores(scores);
+    if (world == 0) throw std::invalid_argument("shard_pairs: world must be at least 1");
     std::vector<double> cost(npairs);
-    for (size_t i = 0; i < npairs; ++i) cost[i] = planner::predicted_pair_cost((size_t)lens[pairs[2 * i]], (size_t)lens[pairs[2 * i + 1]], p);
+    for (size_t i = 0; i < npairs; ++i) {
+      const int64_t a = pairs[2 * i], b = pairs[2 * i + 1];
+      if (a < 0 || b < 0 || (uint64_t)a >= nseq || (uint64_t)b >= nseq)
+        throw std::invalid_argument("shard_pairs: pair " + std::to_string(i) + " names a sequence outside [0, " + std::to_string(nseq) + ")");
+      cost[i] = planner::predicted_pair_cost((size_t)lens[a], (size_t)lens[b], p);
+    }
     const std::vector<uint32_t> sh = planner::assign_shards_lpt(cost, world);
     for (size_t i = 0; i < npairs; ++i) shard_out[i] = sh[i];
     if (cost_out) for (size_t i = 0; i < npairs; ++i) cost_out[i] = cost[i];
     return 0;
   } catch (const std::exception& e) { set_err(err, cap, e.what()); return -1; }
+}
+
+// engine configuration of the engines the host library creates from now on; release = destroy the cached ones first
+void awh_set_engine_config(int flags, int first_row_cols, int release) {
+  if (release) release_engines();
+  set_engine_flags(flags);
+  set_engine_first_row_cols(first_row_cols);
 }
 
 void awh_free(void* p) { free(p); }

@@ -18,7 +18,7 @@ def shard_pairs(pairs, rank, world, lens=None, scores=None):
     (r, r + world, ...), which is what LPT gives for equal-cost lists (configs 2 and 3)."""
     if world <= 1:
         return np.ascontiguousarray(pairs)
-    if lens is None:
+    if lens is None or scores is None:  # (the cost model needs both: without the penalties in use the strided shard is the fallback)
         return np.ascontiguousarray(pairs[rank::world])
     from . import host as H
     shard, _ = H.shard_assignment(pairs, lens, ",".join(str(int(v)) for v in scores), world)

@@ -23,6 +23,8 @@ AWV_F_NO_ARENA_PROBE = 32
 AWV_F_SINGLE_STEP = 64
 AWV_F_NO_CHAIN = 128
 AWV_F_NO_WIDE16 = 256
+AWV_F_NO_DEEP = 512
+AWV_F_NO_RERUN = 1024
 
 #: every symbol include/allwave_hip.h declares
 EXPORTS = ("awv_abi_version", "awv_last_error", "awv_engine_create", "awv_engine_destroy",
@@ -57,7 +59,9 @@ class Stats(C.Structure):
                 ("launches", C.c_uint64), ("cell_steps", C.c_uint64), ("extend_steps", C.c_uint64),
                 ("n_breakpoints", C.c_uint64), ("n_base", C.c_uint64), ("overlap_scans", C.c_uint64),
                 ("aligned_bp", C.c_uint64), ("pairs_completed", C.c_uint64), ("scratch_bytes", C.c_uint64),
-                ("prof", C.c_uint64 * 14), ("restarts", C.c_uint64), ("multi_cell_steps", C.c_uint64), ("windows", C.c_uint64 * 4)]
+                ("prof", C.c_uint64 * 14), ("restarts", C.c_uint64), ("multi_cell_steps", C.c_uint64), ("windows", C.c_uint64 * 4),
+                ("clock_cycles", C.c_uint64), ("clock_ticks", C.c_uint64), ("clock_tick_khz", C.c_uint64),
+                ("deep_cell_steps", C.c_uint64)]
 
 
 PAIR_DTYPE = np.dtype([("q_idx", "<i4"), ("t_idx", "<i4"), ("q_revcomp", "<i4")])

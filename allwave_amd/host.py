@@ -90,6 +90,12 @@ def validate_cigar(ops, qlen, rlen):
     return None if rc == 0 else e.value.decode()
 
 
+def set_engine_config(flags=0, first_row_cols=0, release=True):
+    """awv_engine_config.flags / first_row_cols of the per-device engines the host library creates from now on; `release`
+    destroys the cached engines first, so the next run gets a fresh one under this configuration."""
+    load().awh_set_engine_config(int(flags), int(first_row_cols), int(bool(release)))
+
+
 ORIENT = {"forward": 0, "wfa": 1, "mash": 2}
 
 
@@ -110,6 +116,27 @@ def all_pairs_paf(ids, seqs, scores, orientation="wfa", exclude_self=True, devic
     rc = load().awh_all_pairs_paf(len(ids), cids, data.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p),
                                   scores.encode(), sparsification.encode(), ORIENT[orientation], int(exclude_self),
                                   device, C.byref(out), C.byref(n), e, _CAP)
+    if rc != 0:
+        raise HostError(e.value.decode())
+    txt = C.string_at(out, n.value).decode()
+    load().awh_free(out)
+    return txt.splitlines()
+
+
+ITER_MODES = {"for_each": 0, "next": 1, "par_for_each": 2, "par_collect": 3, "process_alignments": 4}
+
+
+def iterate(ids, seqs, scores, mode="for_each", sparsification="none", orientation="forward", threads=4, chunk=0,
+            resparsify=False, fail_at=-1, device=0):
+    """Every consumer of the pair list (iterator.rs:101-253, lib.rs:57-68) through one hook; returns the PAF lines in arrival
+    order.  `fail_at` >= 0 makes the callback throw at that record: HostError carries its message."""
+    cids, data, offs = _seq_args(ids, seqs)
+    out = C.c_void_p()
+    n, nrec = C.c_size_t(0), C.c_size_t(0)
+    e = _err()
+    rc = load().awh_iterate(len(ids), cids, data.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), scores.encode(),
+                            sparsification.encode(), ORIENT[orientation], ITER_MODES[mode], int(threads), int(chunk), int(bool(resparsify)),
+                            C.c_long(int(fail_at)), device, C.byref(out), C.byref(n), C.byref(nrec), e, _CAP)
     if rc != 0:
         raise HostError(e.value.decode())
     txt = C.string_at(out, n.value).decode()
@@ -184,14 +211,15 @@ def _pairs_out(out, n):
     return [tuple(int(v) for v in r) for r in a]
 
 
-def plan_pairs(ids, seqs, sparsification, exclude_self=True):
-    """Pair list AllPairIterator::with_options would align (iterator.rs:30-92)."""
+def plan_pairs(ids, seqs, sparsification, exclude_self=True, resparsify=False):
+    """Pair list AllPairIterator::with_options would align (iterator.rs:30-92); resparsify: planned with `-p none` first and
+    then through with_sparsification (iterator.rs:101-110)."""
     cids, data, offs = _seq_args(ids, seqs)
     out = C.c_void_p()
     n = C.c_size_t(0)
     e = _err()
     rc = load().awh_plan_pairs(len(ids), cids, data.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p),
-                               sparsification.encode(), int(exclude_self), C.byref(out), C.byref(n), e, _CAP)
+                               sparsification.encode(), int(bool(exclude_self)) | (2 if resparsify else 0), C.byref(out), C.byref(n), e, _CAP)
     if rc != 0:
         raise ValueError(e.value.decode())
     return _pairs_out(out, n.value)
@@ -206,7 +234,7 @@ def shard_assignment(pairs, lens, scores, world):
     shard = np.zeros(len(p), dtype=np.uint32)
     cost = np.zeros(len(p), dtype=np.float64)
     e = _err()
-    rc = load().awh_shard_pairs(p.ctypes.data_as(C.c_void_p), C.c_size_t(len(p)), ln.ctypes.data_as(C.c_void_p), scores.encode(),
+    rc = load().awh_shard_pairs(p.ctypes.data_as(C.c_void_p), C.c_size_t(len(p)), ln.ctypes.data_as(C.c_void_p), C.c_size_t(len(ln)), scores.encode(),
                                 C.c_size_t(int(world)), shard.ctypes.data_as(C.c_void_p), cost.ctypes.data_as(C.c_void_p), e, _CAP)
     if rc != 0:
         raise ValueError(e.value.decode())

@@ -18,11 +18,17 @@ one batch of synthetic input.
 (python -m torch.distributed.run, before anything in this process touches a GPU) and relays rank 0's
 line; under torchrun, --gpus must equal WORLD_SIZE.
 
-Sequences are resident in HBM before the timed region.  `roofline` prices the alignment kernel:
-algorithmic bytes (12 row elements per cell-step for 2-piece = 24 B with 16-bit rows / 48 B with 32-bit
-rows, 7 elements for 1-piece, + CIGAR bytes) over the kernel's HIP-event
-duration, against 8 TB/s HBM3E.  `cpu_baseline` is the CPU restatement (oracle/, kind "port") on a
-bounded sample of the same pairs on this box's host cores, at all cores and at one.
+Sequences are resident in HBM before the timed region.  `roofline` names the unit that binds the alignment
+kernel and the fraction of that unit's peak it runs at, from measured counters: `bound` "valu" (VALU issue:
+SQ_ACTIVE_INST_VALU quad-cycles x 4 / (1024 SIMDs x kernel cycles at the shader clock measured in this run))
+or "hbm" (measured HBM bytes / kernel time against 8 TB/s HBM3E) -- whichever fraction is larger; the
+counters come from the committed rocprofv3 --pmc passes of this command (profiles/pmc_traffic*.json), carried
+over per cell-step; the kernel's duration is measured live (HIP events on the engine's stream).  SURVEY 8(d)'s
+algorithmic bytes (12 row elements per cell-step for 2-piece = 24 B with 16-bit rows / 48 B with 32-bit rows,
+7 elements for 1-piece, + CIGAR bytes) are reported beside it (`algorithmic_GBps`,
+`traffic_over_algorithmic`): since round 2 the kernel keeps rows in registers and moves fewer bytes than that.
+`cpu_baseline` is the CPU restatement (oracle/, kind "port") on a bounded sample of the same pairs on this
+box's host cores, at all cores and at one.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c1|c4|c5] [--pairs P]
 """
@@ -41,7 +47,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PAIRS_PER_GPU = 65280   # config 2's pair count: the per-GPU share of the default multi-GPU workload
 N_SIMDS = 1024          # 256 CUs x 4
-CLOCK_HZ = 2.4e9
+CLOCK_HZ_NOMINAL = 2.4e9  # only when the in-kernel clock stamps are unavailable
 
 
 def usable_cores():
@@ -188,7 +194,7 @@ def main():
     for _ in range(args.warmup):
         res, _ = eng.align_pairs(scores, pairs, want_cigars=False)
     kernel_ms = 0.0
-    launches = cells = multi_cells = ext = bp = done = cig_bytes = restarts = 0
+    launches = cells = multi_cells = ext = bp = done = cig_bytes = restarts = clk_cycles = clk_ticks = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -199,6 +205,8 @@ def main():
         cells += st.cell_steps
         multi_cells += st.multi_cell_steps
         restarts += st.restarts
+        clk_cycles += st.clock_cycles
+        clk_ticks += st.clock_ticks
         ext += st.extend_steps
         bp += st.aligned_bp
         done += st.pairs_completed
@@ -230,29 +238,59 @@ def main():
     kern_s = kernel_ms * 1e-3
     achieved = algo_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
     avg_launch_ms = kernel_ms / max(launches, 1)
-    # HBM bytes and instruction counts per launch come from the committed rocprofv3 --pmc passes of this same
-    # command (profiles/pmc_traffic.json, written by scratch/summarize_pmc.py), NOT from this run: the
-    # counters need the profiler.  Used only when the profile is of this workload and pair count.
-    traffic = valu_frac = hbm_frac_measured = None
-    traffic_source = "none: no committed profile of this workload (run scratch/r02_profile.sh)"
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
+    # HBM bytes and VALU issue cycles come from the committed rocprofv3 --pmc passes of this same command
+    # (profiles/pmc_traffic*.json, written by scratch/summarize_pmc.py), NOT from this run: the counters need the
+    # profiler.  They are carried over per cell-step (bytes and VALU quad-cycles per cell-step are properties of the
+    # kernel on a workload class: c3's reads are c2's) and multiplied by the cell-steps THIS run counted.
+    clk = (clk_cycles / clk_ticks * st.clock_tick_khz * 1e3) if clk_ticks else None  # sustained shader clock of the timed launches, measured in-kernel
+    clock_hz = clk or CLOCK_HZ_NOMINAL
+    cells_per_launch = cells / max(launches, 1)
+    traffic = valu_frac = hbm_frac_measured = valu_per_cell = None
+    counters_source = "none: no committed profile of this workload class (scratch/r03_profile.sh)"
+    tname = {"c2": "pmc_traffic.json", "c3": "pmc_traffic.json", "c1": None, "c4": "pmc_traffic_c4.json", "c5": "pmc_traffic_c5.json"}[cname]
+    tpath = os.path.join(ROOT, "profiles", tname) if tname else None
+    if tpath and os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
-            if t.get("workload") == cname and int(t.get("pairs", 0)) == len(pairs):
-                traffic = t.get("hbm_bytes_per_launch")
-                traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `%s`, FETCH_SIZE x2 per " \
-                                 "profiles/r02/fetch_calibration.json; collected %s, kernel %.0f ms there) -- not measured in this run" \
-                                 % (t.get("command_short", "bench.py --steps 1"), t.get("collected", "?"), t.get("kernel_ms_under_rocprof", 0.0))
-                kcyc = avg_launch_ms * 1e-3 * CLOCK_HZ
-                if t.get("counters", {}).get("SQ_ACTIVE_INST_VALU"):
-                    # quad-cycles x 4 / (SIMDs x kernel cycles); one VALU wave-instruction does cost a SIMD ~4 cycles for this
-                    # kernel's instruction mix (wall-clock microbenchmark, profiles/r02/valu_issue_rates.json)
-                    valu_frac = t["counters"]["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * kcyc)
-                if traffic:
-                    hbm_frac_measured = traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
-        except Exception:
-            traffic = None
+            pcells = float(t["cell_steps_per_launch"])
+            traffic = t["hbm_bytes_per_launch"] / pcells * cells_per_launch
+            counters_source = "%s (rocprofv3 --pmc passes of `%s`, FETCH_SIZE x2 per profiles/r02/fetch_calibration.json; collected %s, " \
+                              "kernel %.0f ms there), carried over per cell-step -- not measured in this run" \
+                              % (os.path.relpath(tpath, ROOT), t.get("command_short", "bench.py --steps 1"), t.get("collected", "?"),
+                                 t.get("kernel_ms_under_rocprof", 0.0))
+            kcyc = avg_launch_ms * 1e-3 * clock_hz
+            q = t.get("counters", {}).get("SQ_ACTIVE_INST_VALU")
+            if q:
+                # quad-cycles x 4 / (SIMDs x kernel cycles); one VALU wave-instruction costs a SIMD ~4 cycles for this kernel's
+                # instruction mix (wall-clock microbenchmark, profiles/r03/valu_issue_rates.json; v_fma_f32 row for reference)
+                valu_frac = q / pcells * cells_per_launch * 4.0 / (N_SIMDS * kcyc)
+            if t.get("counters", {}).get("SQ_INSTS_VALU"):
+                valu_per_cell = t["counters"]["SQ_INSTS_VALU"] / pcells
+            hbm_frac_measured = traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        except Exception as ex:  # a malformed profile must not take the bench line down
+            traffic = valu_frac = hbm_frac_measured = None
+            counters_source = "unreadable profile %s: %s" % (tpath, ex)
+    # The bound is the unit the counters say is busiest.  With no counters the line still has to be a fraction of
+    # something real: the algorithmic bytes against HBM peak, capped at what HBM can be (the cap is flagged).
+    algorithmic_GBps = achieved
+    if valu_frac is not None and hbm_frac_measured is not None and valu_frac >= hbm_frac_measured:
+        peak_rate = N_SIMDS * clock_hz / 4.0 / 1e9  # VALU wave-instructions per ns the chip can issue
+        roof = {"bound": "valu", "achieved": valu_frac * peak_rate, "peak": peak_rate, "unit": "G wave-instr/s", "frac": valu_frac}
+    elif hbm_frac_measured is not None:
+        roof = {"bound": "hbm", "achieved": hbm_frac_measured * HBM_PEAK_GBPS, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_frac_measured}
+    else:
+        roof = {"bound": "hbm", "achieved": min(achieved, HBM_PEAK_GBPS), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": min(achieved / HBM_PEAK_GBPS, 1.0), "uncounted": "no PMC profile: algorithmic bytes / time, capped at peak"}
+    roof.update({"traffic": traffic, "traffic_over_algorithmic": (traffic / (algo_bytes / max(launches, 1))) if traffic else None,
+                 "counters_source": counters_source, "hbm_frac_measured": hbm_frac_measured,
+                 "hbm_GBps_measured": (hbm_frac_measured * HBM_PEAK_GBPS) if hbm_frac_measured is not None else None,
+                 "valu_frac": valu_frac, "valu_insts_per_cell_step": valu_per_cell,
+                 "shader_clock_ghz": (clk / 1e9) if clk else None, "shader_clock_source": "s_memtime / s_memrealtime stamps of every workgroup of the timed launches" if clk else "nominal",
+                 "kernel": "biwfa_align_kernel", "avg_launch_ms": avg_launch_ms,
+                 "cell_steps_per_launch": cells_per_launch, "bytes_per_cell_step": bytes_per_cell,
+                 "algorithmic_bytes_per_launch": algo_bytes / max(launches, 1),
+                 "algorithmic_GBps": algorithmic_GBps,  # SURVEY 8(d)'s figure: what a kernel keeping nothing on chip would have to move, per second (not a fraction of anything)
+                 "multi_step_cell_fraction": multi_cells / max(cells, 1), "restarted_searches_per_launch": restarts / max(launches, 1)})
     out = {
         "metric": "aligned base-pairs/sec (whole node) + PAF lines/sec, all-pairs 10 kbp",
         "value": bp_all / elapsed_max,
@@ -269,15 +307,10 @@ def main():
         "config": {"workload": what,
                    "parallelism": "pairs sharded over %d GPU(s), no collective on the data path" % world},
         "pairs_per_s_kernel": done_all / elapsed_max,
+        "pairs_per_step": len(pairs),
         "per_rank_kernel_ms": per_rank_kernel_ms,
         "kernel_ms_max_over_mean": (max(per_rank_kernel_ms) / (sum(per_rank_kernel_ms) / len(per_rank_kernel_ms))) if per_rank_kernel_ms else None,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                     "hbm_frac_measured": hbm_frac_measured, "valu_frac": valu_frac,
-                     "kernel": "biwfa_align_kernel", "avg_launch_ms": avg_launch_ms,
-                     "cell_steps_per_launch": cells / max(launches, 1), "bytes_per_cell_step": bytes_per_cell,
-                     "algorithmic_bytes_per_launch": algo_bytes / max(launches, 1),
-                     "multi_step_cell_fraction": multi_cells / max(cells, 1), "restarted_searches_per_launch": restarts / max(launches, 1)},
+        "roofline": roof,
     }
 
     if world == 1 and not args.no_paf:
@@ -305,6 +338,11 @@ def main():
                                 "formatting on %d host threads into a counting sink, mean of %d runs (engine already created)"
                                 % (nsub, orient, "mash sketches + " if orient == "mash" else "", thr, len(runs))}
 
+        # the metric's second half, by name: fully formatted PAF lines per second through the boundary, the reference CLI's
+        # default orientation (main.rs:313) -- `pairs_per_s_kernel` above formats no text
+        out["paf_lines_per_s"] = out["paf_end_to_end_mash"]["lines_per_s"]
+        out["paf_lines_per_s_what"] = "paf_end_to_end_mash.lines_per_s (end to end incl. PCIe and host formatting; not part of `value`)"
+
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O  # the reported CPU baseline (kind "port"), never the product
         cores = usable_cores()
@@ -331,8 +369,14 @@ def main():
         mism = int(((g["penalty"] != ores["penalty"]) | (g["cigar_len"] != ores["cigar_len"].astype(np.uint32)) |
                     (g["num_matches"] != ores["num_matches"]) | (g["num_mismatches"] != ores["num_mismatches"]) |
                     (g["num_ins"] != ores["num_ins_text"]) | (g["num_del"] != ores["num_del_pattern"])).sum())
+        # the roofline's unit cross-checked ("counted by the CPU oracle"): the kernel's own cell-step count on exactly
+        # the sampled pairs (one more launch, after the timed region) beside the oracle's on the same pairs
+        eng.align_pairs(scores, sample, want_cigars=False)
+        gcells = int(eng.stats().cell_steps)
         out["parity"] = {"pairs": nsample, "mismatches": mism,
-                         "what": "penalty, cigar_len and M/X/I/D counts vs the CPU oracle on the sampled pairs"}
+                         "what": "penalty, cigar_len and M/X/I/D counts vs the CPU oracle on the sampled pairs",
+                         "cell_steps_kernel_on_sample": gcells, "cell_steps_oracle_on_sample": int(ost.cell_steps),
+                         "cell_steps_kernel_over_oracle": gcells / max(int(ost.cell_steps), 1)}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

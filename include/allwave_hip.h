@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define AWV_ABI_VERSION 2
+#define AWV_ABI_VERSION 3
 
 /* engine-level return codes (negative = failure; never aborts the process) */
 #define AWV_OK 0
@@ -83,6 +83,9 @@ typedef struct {
 #define AWV_F_ONE_WAVE 8       /* always one wave per pair (default: four waves per pair for small batches, long sequences and unequal lengths, sixteen for a few very unequal pairs) */
 #define AWV_F_FOUR_WAVES 16    /* always four waves per pair */
 #define AWV_F_NO_CHAIN 128      /* multi-step passes of one sweep only (no chaining of sweeps through registers) */
+#define AWV_F_NO_RERUN 1024    /* a pair whose wavefronts outgrow the first attempt's rows keeps status AWV_ST_CAPACITY instead of being re-run with
+                                   wider rows (fail fast; with first_row_cols: the way to see a failed pair's record end to end) */
+#define AWV_F_NO_DEEP 512      /* the margin zone of a breakpoint search runs step by step (the round-2 path) instead of in passes that store every I/D row */
 #define AWV_F_SINGLE_STEP 64    /* never use multi-step passes (every step stores all five rows; the round-1 kernel path) */
 #define AWV_F_NO_ARENA_PROBE 32 /* take the first ring-arena allocation as it comes (default: allocate up to four candidates and keep the
                                    one a 1 ms traffic probe finds fastest -- worth up to 6 % of kernel time, costs 1-3 s once per engine:
@@ -148,6 +151,12 @@ typedef struct {
   uint64_t restarts;          /* breakpoint searches run again step by step (multi-step passes met too early) */
   uint64_t multi_cell_steps;  /* cells computed by multi-step passes (I/D rows kept in registers) */
   uint64_t windows[4];        /* window iterations: [0] step-by-step (one step each), [1] multi-step passes (T steps each), [2] base case step-by-step, [3] base case multi-step passes */
+  /* the shader clock the kernels actually ran at (ABI 3): every persistent workgroup stamps s_memtime (shader cycles) and
+   * s_memrealtime (constant-rate ticks, `clock_tick_khz`) when it starts and when it has drained the work queue; summed over the
+   * workgroups of the call's launches.  sustained clock = clock_cycles / clock_ticks * clock_tick_khz kHz */
+  uint64_t clock_cycles, clock_ticks;
+  uint64_t clock_tick_khz;    /* hipDeviceAttributeWallClockRate (100 000 on MI355X) */
+  uint64_t deep_cell_steps;   /* of multi_cell_steps: cells of passes that also store every I/D row (the margin zone before the two searches meet) */
 } awv_stats;
 
 int awv_abi_version(void);

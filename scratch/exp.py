@@ -27,6 +27,6 @@ for r in range(a.reps):
     st = e.stats()
     bad = int((res["status"] != 0).sum())
     print(json.dumps({"tag": a.tag, "flags": a.flags, "rep": r, "pairs": len(pairs), "kernel_ms": round(st.kernel_ms, 2), "Mbp_s": round(st.aligned_bp / st.kernel_ms / 1e3, 1),
-                      "cells": st.cell_steps, "multi_frac": round(st.multi_cell_steps / max(st.cell_steps, 1), 4), "restarts": st.restarts, "win_single": st.windows[0], "win_multi": st.windows[1], "win_base": st.windows[2], "win_base_multi": st.windows[3],
+                      "cells": st.cell_steps, "multi_frac": round(st.multi_cell_steps / max(st.cell_steps, 1), 4), "deep_frac": round(st.deep_cell_steps / max(st.cell_steps, 1), 4), "clock_ghz": round(st.clock_cycles / max(st.clock_ticks, 1) * st.clock_tick_khz / 1e6, 3), "restarts": st.restarts, "win_single": st.windows[0], "win_multi": st.windows[1], "win_base": st.windows[2], "win_base_multi": st.windows[3],
                       "breakpoints": st.n_breakpoints, "bad": bad, "pen_sum": int(res["penalty"].sum()), "launches": st.launches}), flush=True)
 e.close()

@@ -21,7 +21,7 @@ def test_header_symbols_exported(hip_lib):
     assert set(syms) == set(ffi.EXPORTS)
     for s in syms:
         assert getattr(hip_lib, s) is not None, s
-    assert hip_lib.awv_abi_version() == 2
+    assert hip_lib.awv_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
@@ -30,7 +30,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(ffi.Penalties) == 28
     assert ffi.PAIR_DTYPE.itemsize == 12
     assert ffi.RESULT_DTYPE.itemsize == 48
-    assert C.sizeof(ffi.Stats) == 8 * 32
+    assert C.sizeof(ffi.Stats) == 8 * 36
 
 
 def test_flag_and_status_constants_match_header():

@@ -110,6 +110,53 @@ def test_config2_sample_and_invariants(engine, oracle):
         assert rc == 0 and rescored == res["penalty"][i]
 
 
+def test_penalty_is_the_gotoh_optimum(engine, oracle):
+    """The HIP path's penalty against the independent full-DP scorer (oracle/gotoh.c: Gotoh's recurrences, 2-piece), directly
+    -- not through the BiWFA restatement: an exact WFA with no heuristic (alignment.rs:228) must return the optimum.  Random
+    pairs up to 2 kbp of every shape random_pair() draws, all six penalty sets; the CIGAR must re-score to it (wfa.rs:105-176)."""
+    for scores in PENALTY_SETS:
+        rng = random.Random(2200 + len(scores) + scores[1])
+        seqs, pairs = [], []
+        for _ in range(40):
+            s, t = random_pair(rng, maxlen=2000)
+            seqs += [s, t]
+            pairs.append((len(seqs) - 2, len(seqs) - 1))
+        engine.set_sequences(seqs)
+        res, cigs = engine.align_pairs(scores, pairs)
+        for i, (a, b) in enumerate(pairs):
+            want = oracle.gotoh_penalty(seqs[a], seqs[b], scores)
+            assert res["status"][i] == 0 and res["penalty"][i] == want, (scores, i, len(seqs[a]), len(seqs[b]))
+            rc, rescored = oracle.cigar_check(cigs[i], seqs[a], seqs[b], scores)
+            assert rc == 0 and rescored == want, (scores, i)
+
+
+def test_cell_steps_agree_with_the_oracles_count(oracle):
+    """the roofline's unit, C(pair) = sum of (hi - lo + 1) over every compute-next call of the BiWFA tree, is
+    "counted by the CPU oracle"; the bench line uses the kernel's own count (awv_stats.cell_steps).  On the same 96 config-2
+    pairs the two must agree.  Against the oracle in the kernel's mode (known-optimum stop on): the step-by-step kernel
+    computes one row ahead of the official score (+0.2 % measured); with passes, up to T - 1 rows past the end of phase 1
+    (+0.05 %) and a search that met inside a far-apart pass is run again (each restart at most half a pair: +0.5 % of this
+    sample).  Against the oracle's plain WFA2-order search the kernel counts 3-5 % FEWER: the known-optimum stop."""
+    from allwave_amd import ffi, synth
+    data, offs, _ = synth.generate(256, 10000, 0.05, 2)
+    sample = synth.all_pairs(256)[::677][:96]
+    _, ores, ost, _ = oracle.all_pairs(data, offs, sample, DEFAULT_2P, nthreads=8, fast_overlap=True)
+    _, _, ost_plain, _ = oracle.all_pairs(data, offs, sample, DEFAULT_2P, nthreads=8, fast_overlap=False)
+    for flags in (ffi.AWV_F_ONE_WAVE | ffi.AWV_F_SINGLE_STEP, ffi.AWV_F_ONE_WAVE):
+        e = ffi.Engine(flags=flags)
+        try:
+            e.set_sequences((data, offs))
+            res, _ = e.align_pairs(DEFAULT_2P, sample, want_cigars=False)
+            st = e.stats()
+        finally:
+            e.close()
+        assert (res["penalty"] == ores["penalty"]).all()
+        rel = int(st.cell_steps) / int(ost.cell_steps) - 1.0
+        assert 0.0 <= rel < 0.005 + 0.006 * int(st.restarts), (flags, st.cell_steps, ost.cell_steps, st.restarts)
+        rel_plain = int(st.cell_steps) / int(ost_plain.cell_steps) - 1.0
+        assert -0.07 < rel_plain < 0.0, (flags, st.cell_steps, ost_plain.cell_steps)
+
+
 def test_reverse_complement_pairs(engine, oracle):
     """q_revcomp aligns reverse_complement(query) (alignment.rs:178-190): upper-cases, unknown -> N."""
     rng = random.Random(5)

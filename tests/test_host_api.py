@@ -171,3 +171,88 @@ def test_mash_orientation_agrees_with_wfa(host, oracle):
         by = {(l.split("\t")[0], l.split("\t")[5]): l.split("\t")[4] for l in lines}
         for i, rev in enumerate(truth):
             assert by[("qry%d" % i, "ref%d" % i)] == ("-" if rev else "+"), (orient, i)
+
+
+def test_with_sparsification_replans_the_pair_list(host):
+    """iterator.rs:101-110: with_sparsification plans the pair list again through with_options -- the result is the list a
+    direct with_options(strategy) gives, for every strategy (CPU only: planning does not touch the GPU)."""
+    rng = random.Random(5)
+    base = rand_seq(rng, 600)
+    seqs = [mutate(base, 0.03 * (i % 5), rng) for i in range(14)]
+    ids = ["s%02d" % i for i in range(len(seqs))]
+    for strat in ("none", "random:0.4", "giant:0.9", "auto", "tree:2:1:0.1"):
+        direct = host.plan_pairs(ids, seqs, strat)
+        assert host.plan_pairs(ids, seqs, strat, resparsify=True) == direct, strat
+        if strat == "none":
+            assert len(direct) == len(seqs) * (len(seqs) - 1)
+
+
+@pytest.mark.gpu
+def test_every_consumer_of_the_pair_list(host, oracle):
+    """The reference offers five ways to consume the alignments of a pair list: for_each_with_callback (iterator.rs:127-137),
+    the sequential Iterator (:151-171), into_par_iter() with a callback on several threads (:113-125, :206-253) or collected
+    (:182-203), and process_alignments_with_callback (lib.rs:57-68).  All of them must yield the same records -- the
+    oracle's -- in pair-list order where the reference's order is defined (everything but the threaded callback)."""
+    rng = random.Random(77)
+    base = rand_seq(rng, 500)
+    seqs = [base] + [mutate(base, d, rng) for d in (0.02, 0.06, 0.12)] + [rand_seq(rng, 120), b"ACGT" * 30]
+    ids = ["q%d" % i for i in range(len(seqs))]
+    sc = "0,5,8,2,24,1"
+    n = len(seqs)
+    want = [expected_paf(oracle, ids, seqs, i, j, DEFAULT_2P) for i in range(n) for j in range(n) if i != j]
+    assert host.iterate(ids, seqs, sc, mode="for_each") == want
+    assert host.iterate(ids, seqs, sc, mode="next", chunk=7) == want          # several engine calls (30 pairs in chunks of 7)
+    assert host.iterate(ids, seqs, sc, mode="next") == want                    # one engine call
+    assert host.iterate(ids, seqs, sc, mode="par_collect") == want
+    assert sorted(host.iterate(ids, seqs, sc, mode="par_for_each", threads=4)) == sorted(want)
+    # process_alignments_with_callback = with_options(.., exclude_self, mash orientation, strategy): all reads are '+' here
+    assert host.iterate(ids, seqs, sc, mode="process_alignments", orientation="mash") == \
+        host.all_pairs_paf(ids, seqs, sc, orientation="mash")
+    # a sparsified list through with_sparsification: the planned pairs, in plan order, each record the oracle's
+    for strat in ("random:0.5", "tree:1:1:0.2"):
+        plan = host.plan_pairs(ids, seqs, strat)
+        got = host.iterate(ids, seqs, sc, mode="next", chunk=4, sparsification=strat, resparsify=True)
+        assert got == [expected_paf(oracle, ids, seqs, i, j, DEFAULT_2P) for i, j in plan], strat
+
+
+@pytest.mark.gpu
+def test_callback_error_stops_every_consumer(host):
+    """iterator.rs:220-251: the first error a callback returns wins, ends the run and is what the caller sees."""
+    rng = random.Random(3)
+    seqs = [rand_seq(rng, 200) for _ in range(5)]
+    ids = ["e%d" % i for i in range(5)]
+    for mode, kw in (("for_each", {}), ("par_for_each", {"threads": 3}), ("process_alignments", {"orientation": "mash"})):
+        with pytest.raises(host.HostError, match="callback failed at record 6"):
+            host.iterate(ids, seqs, "0,1,1,1", mode=mode, fail_at=6, **kw)
+
+
+@pytest.mark.gpu
+def test_failed_pair_is_an_empty_record(host, oracle):
+    """alignment.rs:49-64 + lib.rs:95-111: a pair whose alignment fails is still a record -- score i32::MAX, no CIGAR, all
+    coordinates zero -- and still a PAF line.  Forced here the only way this engine fails a pair: rows capped at 2048 columns
+    (first_row_cols) and no wider re-run (AWV_F_NO_RERUN), so the divergent 6 kbp pairs stay AWV_ST_CAPACITY while the
+    similar ones complete."""
+    from allwave_amd import ffi
+    rng = random.Random(4242)
+    a = rand_seq(rng, 6000)
+    seqs = [a, mutate(a, 0.08, rng), mutate(a, 0.01, rng)]
+    ids = ["a", "far", "near"]
+    host.set_engine_config(flags=ffi.AWV_F_NO_RERUN, first_row_cols=2048)
+    try:
+        lines = host.all_pairs_paf(ids, seqs, "0,5,8,2,24,1", orientation="forward")
+    finally:
+        host.set_engine_config()  # back to the defaults: the next test gets a fresh engine
+    by = {(l.split("\t")[0], l.split("\t")[5]): l for l in lines}
+    assert len(lines) == 6
+    for q, t in (("a", "far"), ("far", "a"), ("far", "near"), ("near", "far")):
+        qi, ti = ids.index(q), ids.index(t)
+        assert by[(q, t)] == "%s\t%d\t0\t0\t+\t%s\t%d\t0\t0\t0\t0\t60\tgi:f:0.000000\tcg:Z:" % (q, len(seqs[qi]), t, len(seqs[ti])), (q, t)
+    assert by[("a", "near")] == expected_paf(oracle, ids, seqs, 0, 2, DEFAULT_2P)
+    assert by[("near", "a")] == expected_paf(oracle, ids, seqs, 2, 0, DEFAULT_2P)
+    # the same pairs complete when the re-run is allowed
+    host.set_engine_config(first_row_cols=2048)
+    try:
+        lines = host.all_pairs_paf(ids, seqs, "0,5,8,2,24,1", orientation="forward")
+    finally:
+        host.set_engine_config()
+    assert lines[0] == expected_paf(oracle, ids, seqs, 0, 1, DEFAULT_2P)

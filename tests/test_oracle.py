@@ -176,3 +176,25 @@ def test_fast_overlap_mode_is_identical(oracle):
                 cut = rng.randint(0, len(t))
                 t = t[:cut] + rand_seq(rng, rng.randint(20, 600)) + t[cut:]
             assert plain.align(s, t) == fast.align(s, t)
+
+
+def test_pin_files_are_what_the_oracle_gives():
+    """tests/golden/pin/ (the FASTA read sets and expected PAF lines a maintainer diffs against a built allwave, pin.sh) and
+    tests/golden/oracle_kats.tsv (what integration/hip_parity.rs feeds to lib_wfa2) are regenerated in memory and must equal
+    the committed files: a change of the oracle's tie-breaking cannot leave stale pin files behind."""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_pin", os.path.join(here, "golden", "make_pin.py"))
+    mp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mp)
+    for name, cfg_name, nseq, scores in mp.SETS:
+        fasta, paf = mp.build(name, cfg_name, nseq, scores)
+        assert open(os.path.join(here, "golden", "pin", name + ".fa")).read() == fasta, name
+        assert open(os.path.join(here, "golden", "pin", name + ".expected.paf")).read() == paf, name
+        assert len(paf.splitlines()) == nseq * (nseq - 1)
+    import json
+    doc = json.load(open(os.path.join(here, "golden", "oracle_kats.json")))
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(here, "golden", "oracle_kats.tsv")) if not l.startswith("#")]
+    assert len(rows) == len(doc["cases"])
+    for r, c in zip(rows, doc["cases"]):
+        assert r == [c["name"], ",".join(map(str, c["scores"])), c["pattern"], c["text"], str(c["penalty"]), c["cigar"]]

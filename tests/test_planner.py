@@ -301,3 +301,16 @@ def test_cli_reports_write_errors(host, tmp_path):
     assert ok.returncode == 0 and len((tmp_path / "ok.paf").read_text().splitlines()) == 30
     bad = subprocess.run([cli, "-i", str(fa), "-o", "/dev/full", "-p", "none", "--no-progress"], capture_output=True, timeout=300)
     assert bad.returncode != 0 and b"write error" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_cli_reproduces_the_pin_files(host, tmp_path):
+    """The read sets under tests/golden/pin/ through the HIP command-line driver with the reference CLI's flags (pin.sh runs a
+    built allwave the same way): default mash orientation, -p none, the config's scores -- byte-identical PAF lines."""
+    from allwave_amd import build
+    pin = os.path.join(ROOT, "tests", "golden", "pin")
+    for name, scores in (("c1", "0,1,1,1"), ("c2_8x10k", "0,5,8,2,24,1")):
+        out = subprocess.run([build.CLI_BIN, "-i", os.path.join(pin, name + ".fa"), "-p", "none", "-s", scores, "-t", "4", "--no-progress"],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert sorted(out.stdout.splitlines()) == sorted(open(os.path.join(pin, name + ".expected.paf")).read().splitlines()), name
