@@ -459,6 +459,56 @@ __device__ __forceinline__ int packed_first_count(const uint32_t* seq, const Sub
   return (x ? __builtin_clz(x) : 32) >> 1;
 }
 
+// The first probes of the four cells of a lane vector with their LDS reads issued together: left to itself the compiler
+// reuses one register pair for every read and waits for each before issuing the next -- eight LDS round trips per step, in
+// series, about 40 % of a wave's step time.  Here the reads of NB cells (2 NB ds_read2_b32) go out back to back and are
+// waited for once.  (Inline asm: the compiler places no waits around what it cannot see, so the wait is part of the block;
+// it also drains whatever LDS / scalar-memory operation of the compiler's own was in flight, which is harmless.)
+// 1: chained sweeps load their (o2 + e2)-lag M rows one sweep ahead (compute_rows_multi, PREF)
+#ifndef AWV_TAP_PREFETCH
+#define AWV_TAP_PREFETCH 1
+#endif
+#ifndef AWV_PROBE_BATCH
+#define AWV_PROBE_BATCH 2  // cells per batch of LDS reads: 0 = the compiler's own order, 2, 4 (config 2, same box: 1645 / 1629 / 1660 ms)
+#endif
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+template <int DIR, int NB>
+__device__ __forceinline__ void packed_first_counts4(const uint32_t* seq, const SubCtx& cx, const int (&vv)[4], const int (&hh)[4], int (&nn)[4]) {
+  static_assert(NB == 2 || NB == 4, "batch of two or four cells");
+  // LDS byte address of word (pos >> 4) of the staged pattern / text (reverse: the 16 bases that END at len - v, one pad word back)
+  const unsigned baseP = (unsigned)(uintptr_t)(seq + cx.p_w0 - (DIR ? 1 : 0)), baseT = (unsigned)(uintptr_t)(seq + cx.t_w0 - (DIR ? 1 : 0));
+  const int offP = DIR ? cx.p_bit + cx.plen : cx.p_bit, offT = DIR ? cx.t_bit + cx.tlen : cx.t_bit;
+  unsigned aP[4], aT[4], sP[4], sT[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pp = DIR ? offP - vv[j] : offP + vv[j], pt = DIR ? offT - hh[j] : offT + hh[j];
+    aP[j] = baseP + (unsigned)((pp >> 4) << 2);
+    aT[j] = baseT + (unsigned)((pt >> 4) << 2);
+    sP[j] = (unsigned)pp << 1;  // (v_alignbit takes the low five bits: ((pos & 15) * 2))
+    sT[j] = (unsigned)pt << 1;
+  }
+  u32x2_t wP[4], wT[4];
+  if constexpr (NB == 4) {
+    asm volatile("ds_read2_b32 %0, %8 offset1:1\n\tds_read2_b32 %1, %9 offset1:1\n\tds_read2_b32 %2, %10 offset1:1\n\tds_read2_b32 %3, %11 offset1:1\n\t"
+                 "ds_read2_b32 %4, %12 offset1:1\n\tds_read2_b32 %5, %13 offset1:1\n\tds_read2_b32 %6, %14 offset1:1\n\tds_read2_b32 %7, %15 offset1:1\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(wP[0]), "=&v"(wT[0]), "=&v"(wP[1]), "=&v"(wT[1]), "=&v"(wP[2]), "=&v"(wT[2]), "=&v"(wP[3]), "=&v"(wT[3])
+                 : "v"(aP[0]), "v"(aT[0]), "v"(aP[1]), "v"(aT[1]), "v"(aP[2]), "v"(aT[2]), "v"(aP[3]), "v"(aT[3]));
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; g += 2)
+      asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read2_b32 %1, %5 offset1:1\n\tds_read2_b32 %2, %6 offset1:1\n\tds_read2_b32 %3, %7 offset1:1\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(wP[g]), "=&v"(wT[g]), "=&v"(wP[g + 1]), "=&v"(wT[g + 1])
+                   : "v"(aP[g]), "v"(aT[g]), "v"(aP[g + 1]), "v"(aT[g + 1]));
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned x = __builtin_amdgcn_alignbit(wP[j][1], wP[j][0], sP[j]) ^ __builtin_amdgcn_alignbit(wT[j][1], wT[j][0], sT[j]);
+    nn[j] = DIR == 0 ? ((x ? __builtin_ctz(x) : 32) >> 1) : ((x ? __builtin_clz(x) : 32) >> 1);
+  }
+}
+
 // XOR of the next 32 pattern/text bases at (v, h) of direction DIR
 template <int DIR>
 __device__ __forceinline__ uint64_t packed_probe(const uint32_t* seq, const SubCtx& cx, int v, int h) {
@@ -725,6 +775,100 @@ __device__ __forceinline__ void extend_cells_n(const Lds<OffT>& lds, const SubCt
 template <typename OffT>
 __device__ __forceinline__ void extend_cells(const Lds<OffT>& lds, const SubCtx& cx, int dir, int k0, int32_t (&m)[4], unsigned& ext_iters) {
   extend_cells_n<OffT, 4>(lds, cx, dir, k0, m, ext_iters);
+}
+
+// The passes' form of the extension (round 3): bounds test, NULL handling and extension in one go.  cand[j] is the M candidate
+// of diagonal k0 + j as the recurrences leave it (any value; NULLs are negative), ok[j] says whether it is a cell of the
+// wavefront (inside the step's hull and inside the matrix: hmin <= cand <= hmaxv[j], the largest offset inside the matrix on
+// that diagonal).  The remaining length is hmaxv[j] - cand (= min(plen - v, tlen - h)), cells that are not ok probe position 0
+// and come back OFF_NULL: 23 vector instructions per cell where bounds test + extend_cells_n took 34.
+#ifndef AWV_LEAN_EXT
+#define AWV_LEAN_EXT 1
+#endif
+// 1: a search's passes start at score 0 (sources of negative scores are empty rows to plan_multi); 0: round 2's rule, step by
+// step until `scope` - 1 rows exist
+#ifndef AWV_EARLY_PASSES
+#define AWV_EARLY_PASSES 1
+#endif
+// 1: cells that are not part of the wavefront probe wherever their candidate value points instead of position 0 -- an LDS read
+// outside the workgroup's allocation returns 0 on gfx950 (scratch/src/ldsoob.hip: every address tried, no fault), a raw-byte
+// probe cannot do that (global memory): packed probes only
+#ifndef AWV_OOB_PROBES
+#define AWV_OOB_PROBES 0  // measured: 1686 ms against 1673 ms on config 2 (the scattered addresses cost more than the two selects per cell save)
+#endif
+// NBATCH: cells whose first-probe LDS reads go out together (packed_first_counts4; 0: the compiler's own order) -- chosen per
+// instantiation by the caller: only where the registers are there (no spill inside the window loop, scratch/spill_audit.py)
+template <typename OffT, int NBATCH>
+__device__ __forceinline__ void extend_cells_lean(const Lds<OffT>& lds, const SubCtx& cx, int dir, int k0, const int32_t (&cand)[4], const bool (&ok)[4],
+                                                  const int (&hmaxv)[4], int32_t (&m)[4], unsigned& ext_iters) {
+  const uint32_t* seq = lds.seq;
+  int rr[4], vv[4], hh[4], nn[4];
+  // positions of the probes: PROBE_ANYWHERE -- the cell's candidate value as it is (cells that are not ok read somewhere, possibly
+  // outside the LDS allocation, and their count is dropped); otherwise such cells probe position (0, 0)
+  auto positions = [&](bool anywhere) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + j;
+      const bool use = anywhere || ok[j];
+      if constexpr (wenc_of<OffT>()) {  // cand holds w = min(h, v): v = w + max(-k, 0), h = w + max(k, 0)
+        vv[j] = use ? cand[j] + max(-k, 0) : 0;
+        hh[j] = use ? cand[j] + max(k, 0) : 0;
+      } else {
+        vv[j] = use ? cand[j] - k : 0;
+        hh[j] = use ? cand[j] : 0;
+      }
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rr[j] = hmaxv[j] - cand[j];
+  if (cx.seq_mode != 0) {
+    positions(AWV_OOB_PROBES != 0);
+    if constexpr (NBATCH != 0) {
+      if (dir == 0) packed_first_counts4<0, NBATCH ? NBATCH : 4>(seq, cx, vv, hh, nn);
+      else packed_first_counts4<1, NBATCH ? NBATCH : 4>(seq, cx, vv, hh, nn);
+    } else if (dir == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) nn[j] = packed_first_count<0>(seq, cx, vv[j], hh[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) nn[j] = packed_first_count<1>(seq, cx, vv[j], hh[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = min(nn[j], rr[j]);
+      const bool more = ok[j] && t == PROBE_FIRST;  // all sixteen bases matched and at least that many were left (exactly sixteen left: the loop below ends at once)
+      int mo = cand[j] + t;
+      if (more) {
+        const int k = k0 + j;
+        const int v = wenc_of<OffT>() ? mo + max(-k, 0) : mo - k;
+        const int h = wenc_of<OffT>() ? mo + max(k, 0) : mo;
+        mo += dir == 0 ? extend_lcp_packed<0>(seq, cx, v, h, ext_iters) : extend_lcp_packed<1>(seq, cx, v, h, ext_iters);
+      }
+      m[j] = ok[j] ? mo : OFF_NULL;
+    }
+    return;
+  }
+  // raw-byte probes from global memory (sequences that are not pure upper-case ACGT, or too long for the LDS staging)
+  positions(false);
+  const gseq_t Pp = dir ? cx.P[1] : cx.P[0];
+  const gseq_t Tp = dir ? cx.T[1] : cx.T[0];
+  uint64_t xx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xx[j] = ld64u(Pp + (unsigned)vv[j]) ^ ld64u(Tp + (unsigned)hh[j]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = xx[j] ? (int)(__builtin_ctzll(xx[j]) >> 3) : PROBE_BYTES;
+    const int t = min(n, rr[j]);
+    const bool more = ok[j] && t == PROBE_BYTES;
+    int mo = cand[j] + t;
+    if (more) {
+      const int k = k0 + j;
+      const int v = wenc_of<OffT>() ? mo + max(-k, 0) : mo - k;
+      const int h = wenc_of<OffT>() ? mo + max(k, 0) : mo;
+      mo += extend_lcp(Pp, Tp, v, h, cx.plen, cx.tlen, ext_iters);
+    }
+    m[j] = ok[j] ? mo : OFF_NULL;
+  }
 }
 
 // One compute-next + extend step of one direction (A.3 + A.4).  Every lane owns VEC consecutive
@@ -1240,12 +1384,33 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
         }
       }
     }
-    // the last two sweeps' own M rows (canonical stored form), what the next sweeps read 5 / 10 scores back
-    V Mp1[CHAIN ? TM : 1], Mp2[CHAIN && CH >= 3 ? TM : 1];
+    // the last two sweeps' own M rows (canonical stored form), what the next sweeps read 5 / 10 scores back.
+    // 16-bit rows (ALIAS): the same registers ARE the first sweep's sources -- its x- and (o1 + e1)-lag M rows are loaded straight
+    // into Mp1 / Mp2, every step reads its sources there and leaves Mp2[t] = Mp1[t], Mp1[t] = its own row behind: the next sweep's
+    // 5- and 10-back rows without a select per step, a second copy of the sweep's results or a separate set of load registers
+    // (30 registers less than keeping taps, Mp1 / Mp2 and the new rows apart; the (o1 + e1)-lag rows of the second sweep are the
+    // first sweep's x-lag rows -- no load for them either).
+    constexpr bool ALIAS = CHAIN && W16;
+    V Mp1[CHAIN ? TM : 1], Mp2[CHAIN && (ALIAS || CH >= 3) ? TM : 1];
 #pragma unroll
     for (int t = 0; t < (CHAIN ? TM : 1); ++t) Mp1[t] = V{};
 #pragma unroll
-    for (int t = 0; t < (CHAIN && CH >= 3 ? TM : 1); ++t) Mp2[t] = V{};
+    for (int t = 0; t < (CHAIN && (ALIAS || CH >= 3) ? TM : 1); ++t) Mp2[t] = V{};
+    // ALIAS + AWV_TAP_PREFETCH: the one source a chained sweep still loads -- the (o2 + e2)-lag M rows, 25 scores back, written
+    // by earlier passes whatever the sweep -- is loaded a whole sweep ahead: sweep h computes from tapO while tapN (sweep h + 1's)
+    // is in flight, so only a window's first sweep waits for memory.
+    constexpr bool PREF = ALIAS && P2 && (AWV_TAP_PREFETCH != 0);
+    V tapO[PREF ? TM : 1], tapN[PREF ? TM : 1];
+#pragma unroll
+    for (int t = 0; t < (PREF ? TM : 1); ++t) { tapO[t] = V{}; tapN[t] = V{}; }
+    if constexpr (PREF) {
+      if (load_on) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+          if (t < min(TM, Tn)) tapO[t] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, s0 + 1 + t - pn.o2 - pn.e2));
+      }
+    }
+    int win_maxak = INT_MIN / 2;  // max(2 c_j - j) over this window's steps (far-apart passes; folded into lane_maxak below)
     // per cell, the largest / smallest offset inside the matrix on its diagonal (the same for every step of the pass)
     int hmaxv[VEC], hminv[VEC];
 #pragma unroll
@@ -1266,7 +1431,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
       const int sb = s0 + h * TM;   // this sweep covers scores sb + 1 .. sb + TM
       const int tb = h * TM;        // its first step index within the pass
       const int tn = min(TM, Tn - tb);
-      const bool own0 = CHAIN && h >= 1, own1 = CHAIN && CH >= 3 && h >= 2;  // (uniform) M sources 0 / 1 come from registers
+      const bool own0 = CHAIN && h >= 1, own1 = CHAIN && (ALIAS ? h >= 1 : (CH >= 3 && h >= 2));  // (uniform) M sources 0 / 1 come from registers
       // ---- 16-bit rows: all row loads of the sweep, back to back (one memory round trip per sweep).  32-bit rows (a lane
       // vector is four registers; TM x NT of them do not fit): the M sources of a step are loaded one step ahead -- `cur`
       // feeds step t while `nxt` (step t + 1) is in flight; these kernels are bound by HBM bytes, not by the round trips
@@ -1297,9 +1462,16 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
 #pragma unroll
           for (int t = 0; t < TM; ++t) {
             if (t < tn) {
-              if (!own0) tap[t][0] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.x));
-              if (!own1) tap[t][1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o1 - pn.e1));
-              if (P2) tap[t][NT - 1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o2 - pn.e2));
+              if constexpr (ALIAS) {
+                if (!own0) Mp1[t] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.x));
+                if (!own1) Mp2[t] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o1 - pn.e1));
+              } else {
+                if (!own0) tap[t][0] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.x));
+                if (!own1) tap[t][1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o1 - pn.e1));
+              }
+              if constexpr (PREF) {  // the NEXT sweep's rows (a pass of several sweeps is made of whole sweeps)
+                if (h + 1 < nh) tapN[t] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + TM + 1 + t - pn.o2 - pn.e2));
+              } else if (P2) tap[t][NT - 1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o2 - pn.e2));
             }
           }
         }
@@ -1317,9 +1489,15 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
 #pragma unroll
           for (int t = 0; t < TM; ++t) {
             if (t < tn) {
-              if (!own0) lmask(NS0 + tb + t, tap[t][0]);
-              if (!own1) lmask(NS0 + 16 + tb + t, tap[t][1]);
-              if (P2) lmask(NS0 + 32 + tb + t, tap[t][NT - 1]);
+              if constexpr (ALIAS) {
+                if (!own0) lmask(NS0 + tb + t, Mp1[t]);
+                if (!own1) lmask(NS0 + 16 + tb + t, Mp2[t]);
+              } else {
+                if (!own0) lmask(NS0 + tb + t, tap[t][0]);
+                if (!own1) lmask(NS0 + 16 + tb + t, tap[t][1]);
+              }
+              if constexpr (PREF) lmask(NS0 + 32 + tb + t, tapO[t]);
+              else if (P2) lmask(NS0 + 32 + tb + t, tap[t][NT - 1]);
             }
           }
         }
@@ -1331,7 +1509,6 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
       PROF_DRAIN();
       PROF_ADD_L(STAT_T_CR_LOAD, tm0);
       // ---- the steps
-      V Mnew[CHAIN && W16 ? TM : 1];
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
         if (t < tn) {
@@ -1345,13 +1522,20 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             if (t + 1 < TM) load_taps(t + 1, nxt);
           }
           V cMx = W16 ? tap[W16 ? t : 0][0] : cur[0], cO1 = W16 ? tap[W16 ? t : 0][1] : cur[1];
-          const V cO2 = W16 ? tap[W16 ? t : 0][NT - 1] : cur[NT - 1];
-          if (CHAIN) {
+          const V cO2 = PREF ? tapO[PREF ? t : 0] : W16 ? tap[W16 ? t : 0][NT - 1] : cur[NT - 1];
+          if constexpr (ALIAS) {
+            cMx = Mp1[t];
+            cO1 = Mp2[t];
+          } else if (CHAIN) {
             if (own0) cMx = Mp1[t];
             if (CH >= 3 && own1) cO1 = Mp2[CH >= 3 ? t : 0];
           }
           V nI1{}, nD1{}, nI2{}, nD2{};
           int32_t m[VEC];
+#if AWV_LEAN_EXT
+          int32_t cand[VEC];
+          bool okc[VEC];
+#endif
           if constexpr (W16) {
             // max first, neighbour shift after: max(O[k-1], I[k-1]) = (max(O, I))[k-1] -- one shift per gap kind instead of two
             auto pkmax = [&](const V& a, const V& b) {
@@ -1389,7 +1573,12 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
                 lane_oob |= lane_on && mm > hmax;
                 // (h < k, i.e. a negative pattern position, never occurs in a real wavefront; the halo lanes' stale values
                 // -- which are extended like any other now that chained sweeps read them back -- may hold anything)
+#if AWV_LEAN_EXT
+                cand[2 * r + e] = mm;
+                okc[2 * r + e] = in_hull && mm <= hmax && mm >= hminv[2 * r + e];
+#else
                 m[2 * r + e] = (mm > hmax || mm < hminv[2 * r + e] || !in_hull) ? OFF_NULL : mm;
+#endif
               }
             }
           } else {
@@ -1420,7 +1609,12 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
               const int32_t mm = max(del, max((int32_t)cMx.w[j] + 1, ins));
               const int hmax = hmaxv[j];
               lane_oob |= lane_on && mm > hmax;
+#if AWV_LEAN_EXT
+              cand[j] = mm;
+              okc[j] = in_hull && mm <= hmax && mm >= hminv[j];
+#else
               m[j] = (mm > hmax || mm < hminv[j] || !in_hull) ? OFF_NULL : mm;
+#endif
             }
           }
           if (DEEP && lane_on) {  // this score's I/D rows (canonical form), whole lane vectors over the step's hull
@@ -1447,7 +1641,14 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           PROF_DRAIN();
           PROF_ADD_L(STAT_T_CR_ALU, tm1);
           const unsigned long long tm2 = PROF_NOW();
+#if AWV_LEAN_EXT
+          // (batched probe reads where the window loop has the registers for them: the chained far-apart passes -- their first
+          // sweep's sources live in Mp1 / Mp2 -- and the base case; the deep passes' 15 source vectors and the 32-bit rows' four-word
+          // lane vectors leave no room: the compiler's one-read-at-a-time order there)
+          extend_cells_lean<OffT, (W16 && !WE && WG == 64 && (ALIAS || BASE)) ? AWV_PROBE_BATCH : 0>(lds, cx, dir, k0, cand, okc, hmaxv, m, ext_iters);
+#else
           extend_cells_n<OffT, 4, true>(lds, cx, dir, k0, m, ext_iters);
+#endif
           PROF_DRAIN();
           PROF_ADD_L(STAT_T_CR_EXTEND, tm2);
           const unsigned long long tm3 = PROF_NOW();
@@ -1468,15 +1669,25 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
               // the pass's max antidiagonal, reduced once after the last window.  From the clamped values: a NULL is
               // -16384 there, so 2 c - k stays far below any real antidiagonal without a test per cell; cells outside
               // the step's hull are NULL, and the halo lanes' sums are dropped at the end.
+              if constexpr (WE) {
 #pragma unroll
-              for (int j = 0; j < VEC; ++j) {
-                int& mk = DEEPP ? lane_maxak_t[DEEPP ? t : 0] : lane_maxak;
-                if constexpr (WE) mk = max(mk, 2 * m[j] + abs(k0 + j));  // h + v = 2 w + |k| (a NULL is OFF_NULL in m: far below 0; |k| may exceed 16384, so not from the clamped value)
-                else mk = max(mk, (c[j] - (k0 + j)) + c[j]);
+                for (int j = 0; j < VEC; ++j) {
+                  int& mk = DEEPP ? lane_maxak_t[DEEPP ? t : 0] : lane_maxak;
+                  mk = max(mk, 2 * m[j] + abs(k0 + j));  // h + v = 2 w + |k| (a NULL is OFF_NULL in m: far below 0; |k| may exceed 16384, so not from the clamped value)
+                }
+              } else {
+                // h + v = 2 c - (k0 + j): the lane's k0 is the same for every step of the window, so the steps only gather
+                // max(2 c_j - j) (one shift-add per cell, two three-way maxima) and k0 comes off once
+                const int g = max(max(2 * c[0], 2 * c[1] - 1), max(2 * c[2] - 2, 2 * c[3] - 3));
+                if constexpr (DEEPP) lane_maxak_t[t] = max(lane_maxak_t[t], g - k0);
+                else win_maxak = max(win_maxak, g);
               }
             }
             if (lane_on) st(row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t), voff, mv);
-            if constexpr (CHAIN && W16) Mnew[t] = mv;
+            if constexpr (ALIAS) {  // in place: this step has read its entries already
+              Mp2[t] = Mp1[t];
+              Mp1[t] = mv;
+            }
             if constexpr (CHAIN && !W16) {  // in place: this step has read its entries already (the registers of a second copy are not there)
               if (CH >= 3) Mp2[CH >= 3 ? t : 0] = Mp1[t];
               Mp1[t] = mv;
@@ -1507,11 +1718,12 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           }
         }
       }
-      if constexpr (CHAIN && W16) {
+      if constexpr (PREF) {
 #pragma unroll
-        for (int t = 0; t < TM; ++t) { Mp2[t] = Mp1[t]; Mp1[t] = Mnew[t]; }
+        for (int t = 0; t < TM; ++t) tapO[t] = tapN[t];
       }
     }
+    if constexpr (!BASE && !DEEPP && !WE) lane_maxak = max(lane_maxak, win_maxak - k0);
     // ---- the pass's last e1 / e2 I/D rows (canonical form, whole lane vectors over their step's hull)
     if (!DEEP) {
       // queue entry j was produced by step Tn - E + j (Tn >= E); its lanes are those of that step's hull
@@ -2659,7 +2871,7 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
         deep_since[1] = comp[1] + 1;
       }
       if (MULTI_BUILD && !deep_on && phase == 1 && comp[0] == sc[0] && comp[1] == sc[1] && sc[0] == sc[1] &&
-          sc[0] + 1 - (pn.scope - 1) >= 1) {
+          (AWV_EARLY_PASSES || sc[0] + 1 - (pn.scope - 1) >= 1)) {
         // ---- the far-apart phase: all multi-step passes of this search in one call (multi_phase)
         if constexpr (MULTI_BUILD) {
           // (chained sweeps only where the scores allow them: 2-piece with x = TMAX and o1 + e1 = 2 TMAX, the default set)

@@ -901,19 +901,34 @@ void awv_engine_destroy(awv_engine* e) {
   delete e;
 }
 
+// Nothing C++ may cross the C boundary: a std::bad_alloc / std::length_error out of a host-side container (a caller that hands
+// over billions of pairs, a box short of memory) would otherwise reach the foreign caller as std::terminate -> abort().
+#define AWV_GUARDED(body)                                                                                         \
+  try {                                                                                                           \
+    body                                                                                                          \
+  } catch (const std::bad_alloc&) {                                                                               \
+    return fail(AWV_ERR_OOM, "host memory exhausted");                                                            \
+  } catch (const std::exception& ex) {                                                                            \
+    return fail(AWV_ERR_HIP, std::string("internal error: ") + ex.what());                                        \
+  } catch (...) {                                                                                                 \
+    return fail(AWV_ERR_HIP, "internal error: unknown exception");                                                \
+  }
+
 int awv_engine_set_sequences(awv_engine* e, int32_t n, const uint8_t* concat_bytes, const uint64_t* offsets) {
   if (!e) return fail(AWV_ERR_ARG, "null engine");
-  return upload_seqset(e, e->seqs, n, concat_bytes, offsets);
+  AWV_GUARDED(return upload_seqset(e, e->seqs, n, concat_bytes, offsets);)
 }
 
 int awv_align_pairs(awv_engine* e, const awv_penalties* pen, const awv_pair* pairs, int64_t npairs, awv_result* out,
                     awv_sink sink, void* user) {
   if (!e) return fail(AWV_ERR_ARG, "null engine");
   if (e->seqs.n == 0 && npairs > 0) return fail(AWV_ERR_STATE, "align_pairs before set_sequences");
-  return align_core(e, e->seqs, pen, pairs, npairs, out, sink, user);
+  AWV_GUARDED(return align_core(e, e->seqs, pen, pairs, npairs, out, sink, user);)
 }
 
 namespace {
+int align_one_core(awv_engine* e, const awv_penalties* pen, const uint8_t* pattern, int32_t plen, const uint8_t* text,
+                   int32_t tlen, awv_result* result, uint8_t* cigar_buf, size_t cigar_cap);
 struct OneSink {
   uint8_t* buf;
   size_t cap;
@@ -935,24 +950,39 @@ int awv_align_one(awv_engine* e, const awv_penalties* pen, const uint8_t* patter
   if (!e || !result || plen < 0 || tlen < 0 || (plen > 0 && !pattern) || (tlen > 0 && !text))
     return fail(AWV_ERR_ARG, "align_one: bad argument");
   if (cigar_cap < (size_t)plen + (size_t)tlen) return fail(AWV_ERR_ARG, "align_one: cigar buffer needs plen + tlen bytes");
-  SeqSet tmp;
+  AWV_GUARDED(return align_one_core(e, pen, pattern, plen, text, tlen, result, cigar_buf, cigar_cap);)
+}
+}  // extern "C"
+
+namespace {
+int align_one_core(awv_engine* e, const awv_penalties* pen, const uint8_t* pattern, int32_t plen, const uint8_t* text,
+                   int32_t tlen, awv_result* result, uint8_t* cigar_buf, size_t cigar_cap) {
+  struct Scope {  // the temporary sequence set and the engine's flags go back whichever way this function is left
+    awv_engine* e;
+    int32_t saved_flags;
+    SeqSet tmp;
+    ~Scope() {
+      e->cfg.flags = saved_flags;
+      tmp.release();
+    }
+  } sc{e, e->cfg.flags, {}};
   std::vector<uint8_t> cat((size_t)plen + (size_t)tlen + 1);
   if (plen) std::memcpy(cat.data(), pattern, (size_t)plen);
   if (tlen) std::memcpy(cat.data() + plen, text, (size_t)tlen);
   const uint64_t offs[3] = {0, (uint64_t)plen, (uint64_t)plen + (uint64_t)tlen};
-  int rc = upload_seqset(e, tmp, 2, cat.data(), offs);
+  int rc = upload_seqset(e, sc.tmp, 2, cat.data(), offs);
   if (rc == AWV_OK) {
     const awv_pair p{0, 1, 0};
     OneSink os{cigar_buf, cigar_cap, AWV_OK};
-    const int32_t saved_flags = e->cfg.flags;
     e->cfg.flags &= ~AWV_F_KEEP_ON_DEVICE;
-    rc = align_core(e, tmp, pen, &p, 1, result, one_sink, &os);
-    e->cfg.flags = saved_flags;
+    rc = align_core(e, sc.tmp, pen, &p, 1, result, one_sink, &os);
     if (rc == AWV_ERR_SINK && os.rc != AWV_OK) rc = fail(os.rc, "align_one: cigar buffer too small");
   }
-  tmp.release();
   return rc;
 }
+}  // namespace
+
+extern "C" {
 
 int awv_engine_stats(const awv_engine* e, awv_stats* out) {
   if (!e || !out) return fail(AWV_ERR_ARG, "stats: null argument");

@@ -15,7 +15,7 @@ for unit, flags in B.HIP_UNITS:  # every translation unit with the options the l
 funcs = [(i, m.group(1)) for i, l in enumerate(lines) for m in [re.match(r"^(_Z\w+):\s", l)] if m] + [(len(lines), "END")]
 worst = 0
 for (a, name), (b, _) in zip(funcs, funcs[1:]):
-    if "multi_phase" not in name and "base_phase" not in name:
+    if "multi_phase" not in name and "base_phase" not in name and "deep_phase" not in name:
         continue
     body = lines[a:b]
     n = len(body)
