@@ -216,7 +216,12 @@ struct PassCtx {
   int multi_T, lds_seq_bytes, pb_abs, tb_abs;
   int deep_passes;
 };
-struct PhaseResult { int why, sc, fmax, rmax, npass; unsigned long long cells; int sf, sr, last_fwd; };  // sf / sr / last_fwd: deep_phase (official scores where phase 1 ended)
+struct PhaseResult {
+  int why, sc, fmax, rmax, npass;
+  int sf, sr, last_fwd;  // the official scores and the side that advanced last where the phase stopped (sf = sr = sc unless deep_phase ended phase 1)
+  int deep_from;         // every I/D row above this score is in memory (deep_phase began here; = sc when it did not run)
+  unsigned long long cells, deep_cells;  // cells of all the passes / of deep_phase's
+};
 struct Shared {
   Acc acc[3][2];
   int chain_maxak[2][16];  // multi_phase: per direction and step of the running pass, the row's max antidiagonal
@@ -464,6 +469,10 @@ __device__ __forceinline__ int packed_first_count(const uint32_t* seq, const Sub
 // series, about 40 % of a wave's step time.  Here the reads of NB cells (2 NB ds_read2_b32) go out back to back and are
 // waited for once.  (Inline asm: the compiler places no waits around what it cannot see, so the wait is part of the block;
 // it also drains whatever LDS / scalar-memory operation of the compiler's own was in flight, which is harmless.)
+// 1: the first sweep's x- and (o1 + e1)-lag sources are loaded straight into the chain registers (compute_rows_multi, ALIAS)
+#ifndef AWV_CHAIN_ALIAS
+#define AWV_CHAIN_ALIAS 1
+#endif
 // 1: chained sweeps load their (o2 + e2)-lag M rows one sweep ahead (compute_rows_multi, PREF)
 #ifndef AWV_TAP_PREFETCH
 #define AWV_TAP_PREFETCH 1
@@ -1390,7 +1399,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
     // 5- and 10-back rows without a select per step, a second copy of the sweep's results or a separate set of load registers
     // (30 registers less than keeping taps, Mp1 / Mp2 and the new rows apart; the (o1 + e1)-lag rows of the second sweep are the
     // first sweep's x-lag rows -- no load for them either).
-    constexpr bool ALIAS = CHAIN && W16;
+    constexpr bool ALIAS = CHAIN && W16 && (AWV_CHAIN_ALIAS != 0);
     V Mp1[CHAIN ? TM : 1], Mp2[CHAIN && (ALIAS || CH >= 3) ? TM : 1];
 #pragma unroll
     for (int t = 0; t < (CHAIN ? TM : 1); ++t) Mp1[t] = V{};
@@ -1642,10 +1651,11 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           PROF_ADD_L(STAT_T_CR_ALU, tm1);
           const unsigned long long tm2 = PROF_NOW();
 #if AWV_LEAN_EXT
-          // (batched probe reads where the window loop has the registers for them: the chained far-apart passes -- their first
-          // sweep's sources live in Mp1 / Mp2 -- and the base case; the deep passes' 15 source vectors and the 32-bit rows' four-word
-          // lane vectors leave no room: the compiler's one-read-at-a-time order there)
-          extend_cells_lean<OffT, (W16 && !WE && WG == 64 && (ALIAS || BASE)) ? AWV_PROBE_BATCH : 0>(lds, cx, dir, k0, cand, okc, hmaxv, m, ext_iters);
+          // (batched probe reads where the window loop has the registers for them: the base case, and the chained far-apart passes
+          // when they do not spend those registers on loading a sweep ahead -- which pays more: config 2, same box, 1645 ms batched /
+          // 1615 ms a sweep ahead / 1632 ms both (two spills); the deep passes' 15 source vectors and the 32-bit rows' four-word lane
+          // vectors leave no room: the compiler's one-read-at-a-time order there)
+          extend_cells_lean<OffT, (W16 && !WE && WG == 64 && ((ALIAS && !PREF) || BASE)) ? AWV_PROBE_BATCH : 0>(lds, cx, dir, k0, cand, okc, hmaxv, m, ext_iters);
 #else
           extend_cells_n<OffT, 4, true>(lds, cx, dir, k0, m, ext_iters);
 #endif
@@ -1684,8 +1694,8 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
               }
             }
             if (lane_on) st(row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t), voff, mv);
-            if constexpr (ALIAS) {  // in place: this step has read its entries already
-              Mp2[t] = Mp1[t];
+            if constexpr (CHAIN && W16) {  // in place: this step has read its entries already (without ALIAS: only what the next sweeps take from registers)
+              if constexpr (ALIAS || CH >= 3) Mp2[ALIAS || CH >= 3 ? t : 0] = Mp1[t];
               Mp1[t] = mv;
             }
             if constexpr (CHAIN && !W16) {  // in place: this step has read its entries already (the registers of a second copy are not there)
@@ -1787,7 +1797,10 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
 // Inputs beyond the few scalars come from LDS (Shared::pctx), results go back through Shared::pres.
 typedef __attribute__((address_space(3))) Shared* lds_shared_ptr;
 typedef __attribute__((address_space(3))) unsigned char* lds_bytes_ptr;
-constexpr int MP_MARGIN = 0, MP_DISCARD = 1, MP_MET = 2, MP_ERROR = 3;
+constexpr int MP_MARGIN = 0, MP_DISCARD = 1, MP_MET = 2, MP_ERROR = 3, MP_DEEP_MET = 4;
+template <bool P2, typename OffT, int E1, int E2>
+__device__ __attribute__((noinline)) void deep_phase(unsigned sh_addr, unsigned dyn_addr, int s0_v, int fmax_v, int rmax_v, int Tn_v, int pass_v,
+                                                     int far_npass_v, unsigned far_cells_lo, unsigned far_cells_hi);
 // safety margin = BASE + MUL4/4 * (scope + T) * (recent advance per step), in antidiagonal units.  Tuned on config 2
 // (profiles/r02/margin_ab.json): 256 + 2.0 x -> 1926 ms, 26 restarts; 256 + 1.5 x -> 1903 ms, 942 restarts of 979 k searches;
 // 128 + 1.5 x -> 1911 ms, 13 k restarts; 64 + 1.25 x -> 2154 ms, 124 k restarts.
@@ -1799,7 +1812,7 @@ constexpr int MP_MARGIN = 0, MP_DISCARD = 1, MP_MET = 2, MP_ERROR = 3;
 #endif
 constexpr int MARGIN_BASE = AWV_MARGIN_BASE, MARGIN_MUL4 = AWV_MARGIN_MUL4;
 template <bool P2, typename OffT, int E1, int E2, bool CHAIN>
-__device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned dyn_addr, int s0_v, int fmax_v, int rmax_v, int Tn_v, int pass_v) {
+__device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned dyn_addr, int s0_v, int fmax_v, int rmax_v, int Tn_v, int pass_v, int deep_v) {
   Shared& sh = *(Shared*)__builtin_assume_aligned((Shared*)(lds_shared_ptr)(uintptr_t)uni((int)sh_addr), 8);
   unsigned char* dyn_smem = (unsigned char*)__builtin_assume_aligned((unsigned char*)(lds_bytes_ptr)(uintptr_t)uni((int)dyn_addr), 16);
   const int Tn = uni(Tn_v);
@@ -1917,16 +1930,25 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
     PhaseResult& pr = sh.pres;
     pr.why = why;
     pr.sc = sc;
+    pr.sf = pr.sr = sc;
+    pr.last_fwd = 0;
+    pr.deep_from = sc;
     pr.fmax = fmax;
     pr.rmax = rmax;
     pr.npass = npass;
     pr.cells = cells;
+    pr.deep_cells = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { acc_reset(sh.acc[i][0]); acc_reset(sh.acc[i][1]); }  // whatever the caller's pass counter says next, its slot is clean
   }
   if (threadIdx.x < 32) sh.chain_maxak[threadIdx.x >> 4][threadIdx.x & 15] = 0;
   atomicAdd(&sh.ext_multi, (unsigned long long)ext_iters);
   __syncthreads();
+  // The margin is reached: the rest of phase 1 runs in passes that store every I/D row (deep_phase), called from HERE -- a call
+  // site of its own in find_breakpoint_fn cost that function's step-by-step loop register spills (config 5's forced-gap pairs,
+  // which live in that loop: +24 %); its result record replaces the one above and carries the far-apart passes' counts along.
+  if (uni(deep_v) != 0 && why == MP_MARGIN)
+    deep_phase<P2, OffT, E1, E2>(sh_addr, dyn_addr, sc, fmax, rmax, Tn, pass, npass, (unsigned)cells, (unsigned)(cells >> 32));
 }
 
 // The rest of phase 1 in passes (round 3).  From the safety margin on, every I/D row has to be in memory -- the overlap search
@@ -1939,9 +1961,9 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
 // pres.sc the score both directions are COMPUTED through -- the rows beyond the official scores are the ones phase 2 asks for
 // next, already there (nothing reads a row above the official scores, so computing them early changes no result; the ring
 // holds scope + T + 1 rows).  A pass in which a value leaves the matrix is discarded as in multi_phase (MP_DISCARD).
-constexpr int MP_DEEP_MET = 4;
 template <bool P2, typename OffT, int E1, int E2>
-__device__ __attribute__((noinline)) void deep_phase(unsigned sh_addr, unsigned dyn_addr, int s0_v, int fmax_v, int rmax_v, int Tn_v, int pass_v) {
+__device__ __attribute__((noinline)) void deep_phase(unsigned sh_addr, unsigned dyn_addr, int s0_v, int fmax_v, int rmax_v, int Tn_v, int pass_v,
+                                                     int far_npass_v, unsigned far_cells_lo, unsigned far_cells_hi) {
   Shared& sh = *(Shared*)__builtin_assume_aligned((Shared*)(lds_shared_ptr)(uintptr_t)uni((int)sh_addr), 8);
   unsigned char* dyn_smem = (unsigned char*)__builtin_assume_aligned((unsigned char*)(lds_bytes_ptr)(uintptr_t)uni((int)dyn_addr), 16);
   const int Tn = uni(Tn_v);
@@ -1990,6 +2012,8 @@ __device__ __attribute__((noinline)) void deep_phase(unsigned sh_addr, unsigned 
   const int rmask = kp.ring - 1;
   const int max_antidiagonal = cx.plen + cx.tlen - 1;
   int sf = sc, sr = sc, last_fwd = 0;  // official scores and the side that advanced last (WFA2's phase-1 loop, A.6)
+  const int deep_from = sc, far_npass = uni(far_npass_v);
+  const unsigned long long far_cells = ((unsigned long long)(unsigned)uni((int)far_cells_hi) << 32) | (unsigned)uni((int)far_cells_lo);
   int npass = 0, why = MP_DISCARD;
   unsigned long long cells = 0;
   unsigned ext_iters = 0;
@@ -2049,10 +2073,12 @@ __device__ __attribute__((noinline)) void deep_phase(unsigned sh_addr, unsigned 
     pr.sf = sf;
     pr.sr = sr;
     pr.last_fwd = last_fwd;
+    pr.deep_from = deep_from;
     pr.fmax = fmax;
     pr.rmax = rmax;
-    pr.npass = npass;
-    pr.cells = cells;
+    pr.npass = far_npass + npass;
+    pr.cells = far_cells + cells;
+    pr.deep_cells = cells;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { acc_reset(sh.acc[i][0]); acc_reset(sh.acc[i][1]); }
   }
@@ -2875,56 +2901,35 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
         // ---- the far-apart phase: all multi-step passes of this search in one call (multi_phase)
         if constexpr (MULTI_BUILD) {
           // (chained sweeps only where the scores allow them: 2-piece with x = TMAX and o1 + e1 = 2 TMAX, the default set)
-          if (P2) multi_phase<P2, OffT, 2, 1, P2>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
-          else if (pn.e1 == 1) multi_phase<P2, OffT, 1, 1, false>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
-          else multi_phase<P2, OffT, 2, 1, false>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
+          if (P2) multi_phase<P2, OffT, 2, 1, P2>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass, kp.deep_passes);
+          else if (pn.e1 == 1) multi_phase<P2, OffT, 1, 1, false>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass, kp.deep_passes);
+          else multi_phase<P2, OffT, 2, 1, false>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass, kp.deep_passes);
         }
         PROF_ADD(STAT_T_BI_COMPUTE, tp0);
         const int why = uni(sh.pres.why);
         if (why == MP_ERROR) { rc = uni(sh.error); break; }
         if (why == MP_MET) { rc = BP_RESTART; break; }
+        // the far-apart passes and (from the margin on) the passes that store every I/D row, in one call: both directions are
+        // COMPUTED through pres.sc; the official scores may stand below it when phase 1 ended inside the last pass (the rows
+        // beyond them are the ones phase 2 asks for next)
         steps += (long long)(uni(sh.pres.sc) - sc[0]);
-        sc[0] = sc[1] = comp[0] = comp[1] = uni(sh.pres.sc);
+        comp[0] = comp[1] = uni(sh.pres.sc);
+        sc[0] = uni(sh.pres.sf);
+        sc[1] = uni(sh.pres.sr);
+        last_fwd = uni(sh.pres.last_fwd) != 0;
         fmax = uni(sh.pres.fmax);
         rmax = uni(sh.pres.rmax);
         pass += uni(sh.pres.npass);
         {
           const unsigned long long c = ((unsigned long long)(unsigned)uni((int)(sh.pres.cells >> 32)) << 32) | (unsigned)uni((int)sh.pres.cells);
+          const unsigned long long dc = ((unsigned long long)(unsigned)uni((int)(sh.pres.deep_cells >> 32)) << 32) | (unsigned)uni((int)sh.pres.deep_cells);
           cells += c;
           multi_cells += c;
+          deep_cells += dc;
         }
         deep_on = true;  // from here on every row of every component goes to HBM
-        deep_since[0] = comp[0] + 1;
-        deep_since[1] = comp[1] + 1;
-        last_fwd = false;
+        deep_since[0] = deep_since[1] = uni(sh.pres.deep_from) + 1;
         __syncthreads();  // (sh.pres may be rewritten by the next search only after everyone has read it)
-        if (why == MP_MARGIN && kp.deep_passes) {
-          // ---- the rest of phase 1: passes that store every I/D row (deep_phase), until the furthest points can meet
-          const unsigned long long td0 = PROF_NOW();
-          if constexpr (MULTI_BUILD) {
-            if (P2) deep_phase<P2, OffT, 2, 1>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
-            else if (pn.e1 == 1) deep_phase<P2, OffT, 1, 1>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
-            else deep_phase<P2, OffT, 2, 1>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass);
-          }
-          PROF_ADD(STAT_T_BI_COMPUTE, td0);
-          const int dwhy = uni(sh.pres.why);
-          if (dwhy == MP_ERROR) { rc = uni(sh.error); break; }
-          steps += (long long)(uni(sh.pres.sc) - sc[0]);
-          comp[0] = comp[1] = uni(sh.pres.sc);  // computed through here; the official scores may stand below (rows phase 2 asks for next)
-          sc[0] = uni(sh.pres.sf);
-          sc[1] = uni(sh.pres.sr);
-          last_fwd = uni(sh.pres.last_fwd) != 0;
-          fmax = uni(sh.pres.fmax);
-          rmax = uni(sh.pres.rmax);
-          pass += uni(sh.pres.npass);
-          {
-            const unsigned long long c = ((unsigned long long)(unsigned)uni((int)(sh.pres.cells >> 32)) << 32) | (unsigned)uni((int)sh.pres.cells);
-            cells += c;
-            multi_cells += c;
-            deep_cells += c;
-          }
-          __syncthreads();
-        }
         continue;
       } else {
 #pragma unroll
