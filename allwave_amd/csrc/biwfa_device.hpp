@@ -164,6 +164,14 @@ struct Acc { int hull_lo[NCOMP]; int hull_hi[NCOMP]; int maxak; int oob; int rea
 struct Task { int pb, pe, tb, te, cb, ce, score_remaining, known; };  // known: the sub-problem's optimal score (INT_MAX at the top)
 struct Breakpoint { int score, sf, sr, kf, kr, off_f, off_r, comp; };
 
+// Scalar-unit arithmetic, spelled out.  Uniform min / max / add chains whose results end up in vector registers anyway (the data
+// of an LDS store, a per-lane select) are otherwise selected as VALU code wholesale: plan_step's hull arithmetic was ~90 vector
+// instructions per score and direction that way (v_min3 / v_max3 / v_cndmask on values that had just been read into scalar
+// registers), 5 % of everything the kernel issues.  Operands come from v_readlane / scalar loads / constants.
+__device__ __forceinline__ int s_min(int a, int b) { int r; asm("s_min_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
+__device__ __forceinline__ int s_max(int a, int b) { int r; asm("s_max_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
+__device__ __forceinline__ int s_add(int a, int b) { int r; asm("s_add_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
+
 struct alignas(4) RowMeta16 { int16_t lo, hi; };  // (one 32-bit LDS access, also where the compiler cannot see the base's alignment)  // |k| < 32760 whenever 16-bit rows are in use; empty = {1, 0}
 template <typename OffT> struct MetaTraits;
 #ifdef AWV_WIDE16
@@ -179,6 +187,18 @@ __device__ __forceinline__ RowMeta meta_load(const RowMeta16* p) {
 __device__ __forceinline__ RowMeta meta_load(const RowMeta* p) { return *p; }
 __device__ __forceinline__ void meta_store(RowMeta16* p, const RowMeta& m) {
   *p = m.lo > m.hi ? RowMeta16{1, 0} : RowMeta16{(int16_t)m.lo, (int16_t)m.hi};
+}
+// the same for a row whose lo / hi are in scalar registers (plan_step): the stored word(s) are put together on the scalar unit --
+// lo > hi: the empty row -- and one vector move + LDS store per word remain
+__device__ __forceinline__ void meta_store_scalar(RowMeta16* p, int lo, int hi) {
+  int w;
+  asm("s_pack_ll_b32_b16 %0, %1, %2\n\ts_cmp_gt_i32 %1, %2\n\ts_cselect_b32 %0, 1, %0" : "=&s"(w) : "s"(lo), "s"(hi) : "scc");
+  *reinterpret_cast<int*>(p) = w;
+}
+__device__ __forceinline__ void meta_store_scalar(RowMeta* p, int lo, int hi) {
+  int l, h;
+  asm("s_cmp_gt_i32 %2, %3\n\ts_cselect_b32 %0, %4, %2\n\ts_cselect_b32 %1, %5, %3" : "=&s"(l), "=&s"(h) : "s"(lo), "s"(hi), "s"(K_BIG), "s"(-K_BIG) : "scc");
+  *p = RowMeta{l, h};
 }
 __device__ __forceinline__ void meta_store(RowMeta* p, const RowMeta& m) { *p = m; }
 
@@ -224,7 +244,7 @@ struct PhaseResult {
 };
 struct Shared {
   Acc acc[3][2];
-  int chain_maxak[2][16];  // multi_phase: per direction and step of the running pass, the row's max antidiagonal
+  int chain_maxak[2][8];  // per direction: [0] the max antidiagonal of a far-apart pass; [t] of step t of a deep pass (TMAX <= 8)
   PassCtx pctx;
   PhaseResult pres;
   Breakpoint bp_out;  // find_breakpoint_fn's result
@@ -598,7 +618,9 @@ __device__ __forceinline__ void hull_add(RowMeta& h, const RowMeta& s, int dlo, 
   h.hi = max(h.hi, s.hi + dhi);
 }
 
-template <bool P2, bool BASE, typename OffT>
+// SCALAR: the hull arithmetic spelled out for the scalar unit (the passes' planning loop, plan_multi); the step-by-step loop of
+// find_breakpoint_fn keeps the compiler's own selection -- there the extra scalar registers spill (425 spill instructions against 73)
+template <bool P2, bool BASE, typename OffT, bool SCALAR = false>
 __device__ __forceinline__ void plan_step(const KParams& kp, const Lds<OffT>& lds, int dir, int score, StepPlan& pl) {
   const DevPenalties& pn = kp.pen;
   // The nine metadata entries are fetched by nine lanes in one LDS round trip and handed out with
@@ -639,6 +661,36 @@ __device__ __forceinline__ void plan_step(const KParams& kp, const Lds<OffT>& ld
   // repairs in trim_pass): a cell of I (D) is non-NULL iff its left (right) source cell is, M iff
   // any source is (A.3).  They are written to the row metadata right away -- the slot of the new
   // score is not read by anyone during this step -- so nothing but lo/hi outlives the barrier.
+  if constexpr (SCALAR) {
+    // (on the scalar unit by construction -- s_min / s_max / s_add above; an empty source row {K_BIG, -K_BIG} drops out of the
+    // minima / maxima by itself and leaves lo > hi behind where nothing feeds a component)
+    int plo[NCOMP], phi[NCOMP];
+    plo[C_I1] = s_add(s_min(pl.src[1].lo, pl.src[2].lo), 1);
+    phi[C_I1] = s_add(s_max(pl.src[1].hi, pl.src[2].hi), 1);
+    plo[C_D1] = s_add(s_min(pl.src[1].lo, pl.src[3].lo), -1);
+    phi[C_D1] = s_add(s_max(pl.src[1].hi, pl.src[3].hi), -1);
+    plo[C_I2] = plo[C_D2] = K_BIG;
+    phi[C_I2] = phi[C_D2] = -K_BIG;
+    int mlo = s_min(pl.src[0].lo, s_min(plo[C_I1], plo[C_D1])), mhi = s_max(pl.src[0].hi, s_max(phi[C_I1], phi[C_D1]));
+    if (P2) {
+      plo[C_I2] = s_add(s_min(pl.src[4].lo, pl.src[5].lo), 1);
+      phi[C_I2] = s_add(s_max(pl.src[4].hi, pl.src[5].hi), 1);
+      plo[C_D2] = s_add(s_min(pl.src[4].lo, pl.src[6].lo), -1);
+      phi[C_D2] = s_add(s_max(pl.src[4].hi, pl.src[6].hi), -1);
+      mlo = s_min(mlo, s_min(plo[C_I2], plo[C_D2]));
+      mhi = s_max(mhi, s_max(phi[C_I2], phi[C_D2]));
+    }
+    plo[C_M] = mlo;
+    phi[C_M] = mhi;
+    pl.lo = mlo;
+    pl.hi = mhi;
+  #pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      meta_store_scalar(&lds.ring_meta[(dir * NCOMP + c) * kp.ring + (score & (kp.ring - 1))], plo[c], phi[c]);
+      if (BASE && (threadIdx.x & 63) == 0) lds.meta_log[score * NCOMP + c] = plo[c] > phi[c] ? ROW_EMPTY : RowMeta{plo[c], phi[c]};  // history for the backtrace
+    }
+    return;
+  }
   RowMeta pred[NCOMP];
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c) pred[c] = ROW_EMPTY;
@@ -1245,7 +1297,7 @@ __device__ __forceinline__ void plan_multi(const KParams& kp, const Lds<OffT>& l
   mp.vshi = 0;
   for (int t = 0; t < Tn; ++t) {  // (uniform) the predicted metadata of step t is in LDS before step t + 1 is planned
     StepPlan pl;
-    plan_step<P2, BASE, OffT>(kp, lds, dir, s0 + 1 + t, pl);
+    plan_step<P2, BASE, OffT, true>(kp, lds, dir, s0 + 1 + t, pl);
     if (lane == t) { mp.vslo = pl.lo; mp.vshi = pl.hi; }
     if (pl.lo <= pl.hi) {
       mp.lo_min = min(mp.lo_min, pl.lo);
@@ -1888,7 +1940,9 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
 #pragma nounroll
     for (int dir = 0; dir < 2; ++dir) {
       MultiPlan mp;
+      const unsigned long long tpl = PROF_NOW();
       plan_multi<P2, OffT, E1, E2, false>(kp, lds, cx, dir, sc, T, nh, mp);
+      PROF_ADD_L(STAT_T_CR_REDUCE, tpl);  // (diagnostic build: the passes' planning is booked under "reduce")
       Acc& acc = dir ? sh.acc[aslot][1] : sh.acc[aslot][0];
       const int nc = compute_rows_multi<P2, OffT, E1, E2, false, CHAIN>(kp, sh, lds, cx, rs, dir, sc, mp, acc, dir ? sh.chain_maxak[1] : sh.chain_maxak[0], ext_iters);
       if (dir) nc1 = nc; else nc0 = nc;
@@ -1916,7 +1970,7 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
     rmax = max(rmax, P1);
     const bool met = fmax + rmax >= max_antidiagonal;
     __syncthreads();  // everyone has read the pass's maxima
-    if (threadIdx.x < 32) sh.chain_maxak[threadIdx.x >> 4][threadIdx.x & 15] = 0;
+    if (threadIdx.x < 16) sh.chain_maxak[threadIdx.x >> 3][threadIdx.x & 7] = 0;
     if (threadIdx.x == 0) { acc_reset(sh.acc[(pass + 2) % 3][0]); acc_reset(sh.acc[(pass + 2) % 3][1]); }
     __syncthreads();  // ... and they are clear before the next pass adds to them
     ++pass;
@@ -1941,7 +1995,7 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
 #pragma unroll
     for (int i = 0; i < 3; ++i) { acc_reset(sh.acc[i][0]); acc_reset(sh.acc[i][1]); }  // whatever the caller's pass counter says next, its slot is clean
   }
-  if (threadIdx.x < 32) sh.chain_maxak[threadIdx.x >> 4][threadIdx.x & 15] = 0;
+  if (threadIdx.x < 16) sh.chain_maxak[threadIdx.x >> 3][threadIdx.x & 7] = 0;
   atomicAdd(&sh.ext_multi, (unsigned long long)ext_iters);
   __syncthreads();
   // The margin is reached: the rest of phase 1 runs in passes that store every I/D row (deep_phase), called from HERE -- a call
@@ -2023,7 +2077,9 @@ __device__ __attribute__((noinline)) void deep_phase(unsigned sh_addr, unsigned 
 #pragma nounroll
     for (int dir = 0; dir < 2; ++dir) {  // (one copy of the pass code, as in multi_phase)
       MultiPlan mp;
+      const unsigned long long tpl = PROF_NOW();
       plan_multi<P2, OffT, E1, E2, false>(kp, lds, cx, dir, sc, Tn, 1, mp);
+      PROF_ADD_L(STAT_T_CR_REDUCE, tpl);
       Acc& acc = dir ? sh.acc[aslot][1] : sh.acc[aslot][0];
       const int nc = compute_rows_multi<P2, OffT, E1, E2, false, false, true>(kp, sh, lds, cx, rs, dir, sc, mp, acc, dir ? sh.chain_maxak[1] : sh.chain_maxak[0], ext_iters);
       if (dir) nc1 = nc; else nc0 = nc;
@@ -2057,7 +2113,7 @@ __device__ __attribute__((noinline)) void deep_phase(unsigned sh_addr, unsigned 
       }
     }
     __syncthreads();  // everyone has read the pass's maxima
-    if (threadIdx.x < 32) sh.chain_maxak[threadIdx.x >> 4][threadIdx.x & 15] = 0;
+    if (threadIdx.x < 16) sh.chain_maxak[threadIdx.x >> 3][threadIdx.x & 7] = 0;
     if (threadIdx.x == 0) { acc_reset(sh.acc[(pass + 2) % 3][0]); acc_reset(sh.acc[(pass + 2) % 3][1]); }
     __syncthreads();  // ... and they are clear before the next pass adds to them
     ++pass;
@@ -2082,7 +2138,7 @@ __device__ __attribute__((noinline)) void deep_phase(unsigned sh_addr, unsigned 
 #pragma unroll
     for (int i = 0; i < 3; ++i) { acc_reset(sh.acc[i][0]); acc_reset(sh.acc[i][1]); }
   }
-  if (threadIdx.x < 32) sh.chain_maxak[threadIdx.x >> 4][threadIdx.x & 15] = 0;
+  if (threadIdx.x < 16) sh.chain_maxak[threadIdx.x >> 3][threadIdx.x & 7] = 0;
   atomicAdd(&sh.ext_multi, (unsigned long long)ext_iters);
   __syncthreads();
 }
@@ -3127,7 +3183,7 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
   if (tid < 5) sh.prof[tid] = 0;
 #endif
   const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
-  if (tid < 32) sh.chain_maxak[tid >> 4][tid & 15] = 0;
+  if (tid < 16) sh.chain_maxak[tid >> 3][tid & 7] = 0;
   __syncthreads();
   for (;;) {
     if (tid == 0) {
