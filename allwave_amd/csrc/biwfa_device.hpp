@@ -493,6 +493,18 @@ __device__ __forceinline__ int packed_first_count(const uint32_t* seq, const Sub
 #ifndef AWV_CHAIN_ALIAS
 #define AWV_CHAIN_ALIAS 1
 #endif
+// 1: 32-bit rows (long sequences): the (o1 + e1)-lag M rows of a chained pass's later sweeps live in LDS -- a lane vector is four
+// registers there and a second set of chain registers does not fit; the staging region of the packed sequences is free whenever
+// the sub-problem is too long to be staged (the top BiWFA levels of 100 kbp reads), and five scores x 64 lanes x 16 B per wave
+// fit it.  Passes then chain three sweeps (15 scores) instead of two: 52 row vectors per 15 scores move through HBM instead of 70.
+#ifndef AWV_LDS_CHAIN
+#define AWV_LDS_CHAIN 1
+#endif
+// 1: the last sweep of a window issues the NEXT window's first-sweep loads, step by step, into the chain registers its own
+// steps have just finished with (compute_rows_multi, XPREF; needs AWV_TAP_PREFETCH)
+#ifndef AWV_WINDOW_PREFETCH
+#define AWV_WINDOW_PREFETCH 0  // bit-exact, measured twice on config 2: -1.0 % and 0.0 % (1795 -> 1777 / 1797 ms): a window's first burst is not where the waves wait; off
+#endif
 // 1: chained sweeps load their (o2 + e2)-lag M rows one sweep ahead (compute_rows_multi, PREF)
 #ifndef AWV_TAP_PREFETCH
 #define AWV_TAP_PREFETCH 1
@@ -1259,6 +1271,7 @@ struct MultiPlan {
   int vslo, vshi;            // VGPR: lane t = predicted hull of step t (score s0 + 1 + t) in diagonals; lo > hi: empty
   int int_lo, int_hi;        // window origins whose 64 lane vectors lie inside every source's stored hull
   int end_comp, end_col;     // base case: component and column of the end cell (k = tlen - plen); end_col < 0: no termination test
+  int lds_chain;             // 32-bit rows: 1 = the previous sweep's x-lag rows are kept in LDS (Lds::seq, unused by this sub-problem) for the next sweep
 };
 
 // source r of a pass that starts after score s0: which component at which score.  Lanes 0 .. NS0-1 are the
@@ -1293,6 +1306,7 @@ __device__ __forceinline__ void plan_multi(const KParams& kp, const Lds<OffT>& l
   mp.hi_max = -K_BIG;
   mp.end_comp = C_M;
   mp.end_col = -1;
+  mp.lds_chain = 0;
   mp.vslo = 1;
   mp.vshi = 0;
   for (int t = 0; t < Tn; ++t) {  // (uniform) the predicted metadata of step t is in LDS before step t + 1 is planned
@@ -1409,9 +1423,22 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
     return o;
   };
   int nwin = 0;
+  // (declared out here: with XPREF these registers carry the next window's first-sweep sources across the window loop)
+  constexpr bool ALIAS = CHAIN && W16 && (AWV_CHAIN_ALIAS != 0);
+  constexpr bool PREF = ALIAS && P2 && (AWV_TAP_PREFETCH != 0);
+  constexpr bool XPREF = PREF && (AWV_WINDOW_PREFETCH != 0);
+  V Mp1[CHAIN ? TM : 1], Mp2[CHAIN && (ALIAS || CH >= 3) ? TM : 1];
+  V tapO[PREF ? TM : 1], tapN[PREF ? TM : 1];
+  bool pre_loaded = false;  // (uniform) XPREF: the previous window has issued this window's first-sweep loads
+  constexpr bool LCH = CHAIN && !W16 && (AWV_LDS_CHAIN != 0);
+  const bool lds_chain = LCH && mp.lds_chain != 0;  // (uniform)
+  typedef unsigned int u32x4l __attribute__((ext_vector_type(4)));
+  // this wave's slots: [step of the sweep][lane], 16 B each (the region is 16-byte aligned: Lds::seq starts at a 16-byte multiple)
+  u32x4l* const chain_slot = reinterpret_cast<u32x4l*>(const_cast<uint32_t*>(lds.seq)) + (size_t)(threadIdx.x >> 6) * (TM * 64) + lane;
   for (int cb = (colLoMin & ~(VEC - 1)) - halo * VEC + (NWAVES > 1 ? (int)(threadIdx.x >> 6) * stride : 0); cb + halo * VEC <= colHiMax;
        cb += stride * NWAVES) {
     ++nwin;
+    const bool has_next = XPREF && cb + stride * NWAVES + halo * VEC <= colHiMax;  // (uniform) this wave has another window in this pass
     const int c0 = cb + lane * VEC;
     const int k0 = c0 + kmin;
     const int voff = c0 * ESZ;
@@ -1451,21 +1478,22 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
     // 5- and 10-back rows without a select per step, a second copy of the sweep's results or a separate set of load registers
     // (30 registers less than keeping taps, Mp1 / Mp2 and the new rows apart; the (o1 + e1)-lag rows of the second sweep are the
     // first sweep's x-lag rows -- no load for them either).
-    constexpr bool ALIAS = CHAIN && W16 && (AWV_CHAIN_ALIAS != 0);
-    V Mp1[CHAIN ? TM : 1], Mp2[CHAIN && (ALIAS || CH >= 3) ? TM : 1];
+    if (!(XPREF && pre_loaded)) {
 #pragma unroll
-    for (int t = 0; t < (CHAIN ? TM : 1); ++t) Mp1[t] = V{};
+      for (int t = 0; t < (CHAIN ? TM : 1); ++t) Mp1[t] = V{};
 #pragma unroll
-    for (int t = 0; t < (CHAIN && (ALIAS || CH >= 3) ? TM : 1); ++t) Mp2[t] = V{};
+      for (int t = 0; t < (CHAIN && (ALIAS || CH >= 3) ? TM : 1); ++t) Mp2[t] = V{};
+    }
     // ALIAS + AWV_TAP_PREFETCH: the one source a chained sweep still loads -- the (o2 + e2)-lag M rows, 25 scores back, written
     // by earlier passes whatever the sweep -- is loaded a whole sweep ahead: sweep h computes from tapO while tapN (sweep h + 1's)
     // is in flight, so only a window's first sweep waits for memory.
-    constexpr bool PREF = ALIAS && P2 && (AWV_TAP_PREFETCH != 0);
-    V tapO[PREF ? TM : 1], tapN[PREF ? TM : 1];
 #pragma unroll
-    for (int t = 0; t < (PREF ? TM : 1); ++t) { tapO[t] = V{}; tapN[t] = V{}; }
+    for (int t = 0; t < (PREF ? TM : 1); ++t) {
+      if (!(XPREF && pre_loaded)) tapO[t] = V{};
+      tapN[t] = V{};
+    }
     if constexpr (PREF) {
-      if (load_on) {
+      if (load_on && !(XPREF && pre_loaded)) {
 #pragma unroll
         for (int t = 0; t < TM; ++t)
           if (t < min(TM, Tn)) tapO[t] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, s0 + 1 + t - pn.o2 - pn.e2));
@@ -1492,7 +1520,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
       const int sb = s0 + h * TM;   // this sweep covers scores sb + 1 .. sb + TM
       const int tb = h * TM;        // its first step index within the pass
       const int tn = min(TM, Tn - tb);
-      const bool own0 = CHAIN && h >= 1, own1 = CHAIN && (ALIAS ? h >= 1 : (CH >= 3 && h >= 2));  // (uniform) M sources 0 / 1 come from registers
+      const bool own0 = CHAIN && h >= 1, own1 = CHAIN && (ALIAS || lds_chain ? h >= 1 : (CH >= 3 && h >= 2));  // (uniform) M sources 0 / 1 come from registers (or, 32-bit rows, from LDS)
       // ---- 16-bit rows: all row loads of the sweep, back to back (one memory round trip per sweep).  32-bit rows (a lane
       // vector is four registers; TM x NT of them do not fit): the M sources of a step are loaded one step ahead -- `cur`
       // feeds step t while `nxt` (step t + 1) is in flight; these kernels are bound by HBM bytes, not by the round trips
@@ -1524,8 +1552,10 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           for (int t = 0; t < TM; ++t) {
             if (t < tn) {
               if constexpr (ALIAS) {
-                if (!own0) Mp1[t] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.x));
-                if (!own1) Mp2[t] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o1 - pn.e1));
+                if (!own0 && !(XPREF && pre_loaded)) {  // (own0 = own1 here: the first sweep only; with XPREF the previous window may have issued them)
+                  Mp1[t] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.x));
+                  Mp2[t] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o1 - pn.e1));
+                }
               } else {
                 if (!own0) tap[t][0] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.x));
                 if (!own1) tap[t][1] = buf_load_raw<OffT>(rs, voff, row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t - pn.o1 - pn.e1));
@@ -1589,7 +1619,22 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             cO1 = Mp2[t];
           } else if (CHAIN) {
             if (own0) cMx = Mp1[t];
-            if (CH >= 3 && own1) cO1 = Mp2[CH >= 3 ? t : 0];
+            if constexpr (LCH) {
+              if (lds_chain) {  // this step's (o1 + e1)-lag source out of the slot, its x-lag source -- the next sweep's (o1 + e1)-lag source -- into it (LDS operations of a wave complete in order)
+                if (own1) {
+                  const u32x4l w4 = chain_slot[t * 64];
+#pragma unroll
+                  for (int j = 0; j < NW; ++j) cO1.w[j] = w4[j & 3];
+                }
+                if (h + 1 < nh) {
+                  u32x4l w4;
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) w4[j] = cMx.w[j & (NW - 1)];
+                  chain_slot[t * 64] = w4;
+                }
+              }
+            }
+            if (CH >= 3 && own1 && !lds_chain) cO1 = Mp2[CH >= 3 ? t : 0];
           }
           V nI1{}, nD1{}, nI2{}, nD2{};
           int32_t m[VEC];
@@ -1747,8 +1792,23 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
             }
             if (lane_on) st(row_off<BASE, OffT>(kp, dir, C_M, sb + 1 + t), voff, mv);
             if constexpr (CHAIN && W16) {  // in place: this step has read its entries already (without ALIAS: only what the next sweeps take from registers)
-              if constexpr (ALIAS || CH >= 3) Mp2[ALIAS || CH >= 3 ? t : 0] = Mp1[t];
-              Mp1[t] = mv;
+              if (XPREF && has_next && h == nh - 1) {
+                // the window's last sweep: nobody reads this step's chain registers again -- they take the NEXT window's first-sweep
+                // sources of the same step (its loads are then a whole sweep old when that window starts)
+                const int voff_n = voff + stride * NWAVES * ESZ, c0_n = c0 + stride * NWAVES;
+                const bool load_on_n = c0_n + (halo + 2) * VEC > colLoMin && c0_n - (halo + 1) * VEC <= colHiMax;
+                Mp1[t] = V{};
+                Mp2[XPREF ? t : 0] = V{};
+                tapO[XPREF ? t : 0] = V{};
+                if (load_on_n) {
+                  Mp1[t] = buf_load_raw<OffT>(rs, voff_n, row_off<BASE, OffT>(kp, dir, C_M, s0 + 1 + t - pn.x));
+                  Mp2[XPREF ? t : 0] = buf_load_raw<OffT>(rs, voff_n, row_off<BASE, OffT>(kp, dir, C_M, s0 + 1 + t - pn.o1 - pn.e1));
+                  tapO[XPREF ? t : 0] = buf_load_raw<OffT>(rs, voff_n, row_off<BASE, OffT>(kp, dir, C_M, s0 + 1 + t - pn.o2 - pn.e2));
+                }
+              } else {
+                if constexpr (ALIAS || CH >= 3) Mp2[ALIAS || CH >= 3 ? t : 0] = Mp1[t];
+                Mp1[t] = mv;
+              }
             }
             if constexpr (CHAIN && !W16) {  // in place: this step has read its entries already (the registers of a second copy are not there)
               if (CH >= 3) Mp2[CH >= 3 ? t : 0] = Mp1[t];
@@ -1781,10 +1841,13 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
         }
       }
       if constexpr (PREF) {
+        if (!(XPREF && has_next && h == nh - 1)) {
 #pragma unroll
-        for (int t = 0; t < TM; ++t) tapO[t] = tapN[t];
+          for (int t = 0; t < TM; ++t) tapO[t] = tapN[t];
+        }
       }
     }
+    pre_loaded = has_next;
     if constexpr (!BASE && !DEEPP && !WE) lane_maxak = max(lane_maxak, win_maxak - k0);
     // ---- the pass's last e1 / e2 I/D rows (canonical form, whole lane vectors over their step's hull)
     if (!DEEP) {
@@ -1917,7 +1980,10 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
   int nsteps = 0, npass = 0, why = MP_MARGIN;
   unsigned long long cells = 0;
   unsigned ext_iters = 0;
-  const int chain_cap = CHAIN ? min(max(uni(pc.chain_max), 1), sizeof(OffT) == 2 ? CHAIN_MAX : CHAIN_MAX32) : 1;
+  // 32-bit rows: a third chained sweep when the staging region of the packed sequences can hold the chain rows (AWV_LDS_CHAIN)
+  const bool lds_chain = CHAIN && sizeof(OffT) == 4 && (AWV_LDS_CHAIN != 0) && cx.seq_mode == 0 &&
+                         uni(pc.lds_seq_bytes) >= (WG / 64) * TMAX32 * 64 * 16;
+  const int chain_cap = CHAIN ? min(max(uni(pc.chain_max), 1), sizeof(OffT) == 2 ? CHAIN_MAX : (lds_chain ? 3 : CHAIN_MAX32)) : 1;
   for (;;) {
     // Start keeping every I/D row well before the furthest points can meet: the margin is several times what
     // the two searches advance while `scope` more rows (and one more pass) are computed.  The longest chain
@@ -1942,6 +2008,7 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
       MultiPlan mp;
       const unsigned long long tpl = PROF_NOW();
       plan_multi<P2, OffT, E1, E2, false>(kp, lds, cx, dir, sc, T, nh, mp);
+      mp.lds_chain = lds_chain ? 1 : 0;
       PROF_ADD_L(STAT_T_CR_REDUCE, tpl);  // (diagnostic build: the passes' planning is booked under "reduce")
       Acc& acc = dir ? sh.acc[aslot][1] : sh.acc[aslot][0];
       const int nc = compute_rows_multi<P2, OffT, E1, E2, false, CHAIN>(kp, sh, lds, cx, rs, dir, sc, mp, acc, dir ? sh.chain_maxak[1] : sh.chain_maxak[0], ext_iters);

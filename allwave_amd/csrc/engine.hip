@@ -590,7 +590,9 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       // 32-bit rows: sweeps of at most TMAX32 scores, at most CHAIN_MAX32 of them chained (a lane vector is four registers)
       kp.multi_T = narrow ? multi_T : (std::min(multi_T, awv::TMAX32) >= 2 ? std::min(multi_T, awv::TMAX32) : 0);
       kp.deep_passes = (kp.multi_T > 0 && !(e->cfg.flags & AWV_F_NO_DEEP)) ? 1 : 0;
-      kp.chain_max = narrow ? chain_max : (awv::TMAX32 == awv::TMAX ? std::min(chain_max, awv::CHAIN_MAX32) : 1);
+      // (32-bit rows: two sweeps chained through registers, a third when the kernel finds room for its chain rows in LDS -- the
+      // kernel caps what it is offered: biwfa_device.hpp, AWV_LDS_CHAIN)
+      kp.chain_max = narrow ? chain_max : (awv::TMAX32 == awv::TMAX ? std::min(chain_max, 3) : 1);
       kp.wcap = wc;
       kp.ring_mem = e->ring_mem.p;
       kp.ring_slot_stride = ring_stride;
@@ -713,6 +715,9 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
         const int dl = std::abs(ql - tl);
         int f = (all_wide || (!never_wide && (dl >= 4096 || std::max(ql, tl) >= 32760))) ? 1 : 0;
         if (use_sixteen && dl >= 16384) f = 2;  // a forced gap that long: rows hundreds of windows wide
+#ifdef AWV_DEBUG_KNOBS
+        if (getenv("AWV_FORCE_SIXTEEN") && std::max(ql, tl) >= atoi(getenv("AWV_FORCE_SIXTEEN"))) f = 2;  // experiment: sixteen waves per pair for sequences at least that long
+#endif
         fl[(size_t)i] = (uint8_t)f;
         n_one += f == 0;
         n_four += f == 1;

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT; T=${1:-v}; C=${2:-c2}; O=$R/gpurun_out; mkdir -p $O
 CF=""; [ "$C" != "c2" ] && CF="--config $C"
 PT=${PASS_TIMEOUT:-300}
 if [ -z "$3" ]; then
-  cd $R && timeout -k 10 900 python bench.py $CF > $O/bench_$T.json 2> $O/bench_$T.err || { tail -5 $O/bench_$T.err; exit 1; }
+  cd $R && timeout -k 10 900 python bench.py $CF $BENCH_ARGS > $O/bench_$T.json 2> $O/bench_$T.err || { tail -5 $O/bench_$T.err; exit 1; }
 fi
 cd /tmp; export TMPDIR=/tmp
 CMD="python3 $R/bench.py $CF --steps 1 --warmup 0 --no-cpu-baseline --no-paf"

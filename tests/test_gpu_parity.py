@@ -337,6 +337,32 @@ def test_long_sequences_use_32bit_rows(engine, oracle):
     assert st.n_breakpoints > 10 and st.pairs_completed == 4
 
 
+def test_unstaged_long_pairs_chain_through_lds(oracle):
+    """70 kbp at 2 %: 32-bit rows, four waves per pair, and a top BiWFA level too long for the LDS staging of the packed sequences
+    (140 k bases against the 32 KB region) -- the regime in which the far-apart passes chain three sweeps with the middle
+    sweep's rows kept in that region (AWV_LDS_CHAIN, biwfa_device.hpp).  Against the oracle, and against the same engine with
+    chaining off (AWV_F_NO_CHAIN)."""
+    from allwave_amd import ffi
+    rng = random.Random(1234)
+    a = rand_seq(rng, 70000)
+    b = mutate(a, 0.02, rng)
+    c = mutate(a, 0.03, rng)
+    seqs = [a, b, c]
+    pairs = [(0, 1), (1, 2), (2, 0)]
+    out = []
+    for flags in (0, ffi.AWV_F_NO_CHAIN):
+        e = ffi.Engine(flags=flags)
+        try:
+            check_against_oracle(e, oracle, seqs, pairs, DEFAULT_2P)
+            st = e.stats()
+            assert st.multi_cell_steps > 0.8 * st.cell_steps
+            res, cigs = e.align_pairs(DEFAULT_2P, pairs)
+            out.append((res["penalty"].tolist(), cigs))
+        finally:
+            e.close()
+    assert out[0] == out[1]
+
+
 def test_narrow_first_attempt_is_rerun_with_wider_rows(oracle):
     """Long sequences start with rows narrower than plen + tlen; pairs whose wavefronts outgrow them
     come back CAPACITY from the first launch and are re-run wider.  Forced here on 6 kbp pairs by
