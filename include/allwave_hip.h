@@ -75,21 +75,24 @@ typedef struct {
   int64_t max_scratch_bytes; /* cap on the per-workgroup wavefront arenas (0 = default 160 GiB) */
 } awv_engine_config;
 
+/* ---- flags a caller has a use for */
 #define AWV_F_KEEP_ON_DEVICE 1 /* do not copy CIGARs back (kernel-only measurements) */
+#define AWV_F_NO_ARENA_PROBE 32 /* take the first ring-arena allocation as it comes (default: allocate up to four candidates and keep the
+                                   one a 1 ms traffic probe finds fastest -- worth up to 6 % of kernel time, costs 1-3 s once per engine:
+                                   for short-lived processes with little work) */
+#define AWV_F_NO_RERUN 1024    /* a pair whose wavefronts outgrow the first attempt's rows keeps status AWV_ST_CAPACITY instead of being re-run with
+                                   wider rows (fail fast; with first_row_cols: the way to see a failed pair's record end to end) */
+/* ---- variant pins: tests and A/B measurements only.  Results are identical under every one of them (tests/test_gpu_parity.py
+ * runs the pairs of variants against each other and against the oracle); a product caller leaves them alone. */
 #define AWV_F_FORCE_INT32 2    /* always use 32-bit wavefront rows (default: 16-bit when lengths < 32760, and -- in the
                                   four- and sixteen-wave flavours -- when only the shorter length is: rows of min(h, v)) */
 #define AWV_F_NO_WIDE16 256    /* 32-bit rows whenever the longer sequence has 32760 bases or more (no min(h, v) rows) */
 #define AWV_F_NO_PACKED_SEQ 4  /* never stage 2-bit packed sequences in LDS (raw-byte probes from HBM only) */
 #define AWV_F_ONE_WAVE 8       /* always one wave per pair (default: four waves per pair for small batches, long sequences and unequal lengths, sixteen for a few very unequal pairs) */
 #define AWV_F_FOUR_WAVES 16    /* always four waves per pair */
-#define AWV_F_NO_CHAIN 128      /* multi-step passes of one sweep only (no chaining of sweeps through registers) */
-#define AWV_F_NO_RERUN 1024    /* a pair whose wavefronts outgrow the first attempt's rows keeps status AWV_ST_CAPACITY instead of being re-run with
-                                   wider rows (fail fast; with first_row_cols: the way to see a failed pair's record end to end) */
+#define AWV_F_NO_CHAIN 128     /* multi-step passes of one sweep only (no chaining of sweeps through registers / LDS) */
 #define AWV_F_NO_DEEP 512      /* the margin zone of a breakpoint search runs step by step (the round-2 path) instead of in passes that store every I/D row */
-#define AWV_F_SINGLE_STEP 64    /* never use multi-step passes (every step stores all five rows; the round-1 kernel path) */
-#define AWV_F_NO_ARENA_PROBE 32 /* take the first ring-arena allocation as it comes (default: allocate up to four candidates and keep the
-                                   one a 1 ms traffic probe finds fastest -- worth up to 6 % of kernel time, costs 1-3 s once per engine:
-                                   for short-lived processes with little work) */
+#define AWV_F_SINGLE_STEP 64   /* never use multi-step passes (every step stores all five rows; the round-1 kernel path) */
 
 /* penalties as allwave passes them to lib_wfa2 (src/alignment.rs:263-289) */
 typedef struct {
