@@ -489,6 +489,11 @@ __device__ __forceinline__ int packed_first_count(const uint32_t* seq, const Sub
 // series, about 40 % of a wave's step time.  Here the reads of NB cells (2 NB ds_read2_b32) go out back to back and are
 // waited for once.  (Inline asm: the compiler places no waits around what it cannot see, so the wait is part of the block;
 // it also drains whatever LDS / scalar-memory operation of the compiler's own was in flight, which is harmless.)
+// 1: plan_multi plans a pass's steps without an LDS round trip per step (I/D metadata forwarded in scalar registers, M rows
+// fetched an iteration ahead); 0: one plan_step per score
+#ifndef AWV_PLAN_PIPELINED
+#define AWV_PLAN_PIPELINED 1
+#endif
 // 1: the first sweep's x- and (o1 + e1)-lag sources are loaded straight into the chain registers (compute_rows_multi, ALIAS)
 #ifndef AWV_CHAIN_ALIAS
 #define AWV_CHAIN_ALIAS 1
@@ -1309,6 +1314,89 @@ __device__ __forceinline__ void plan_multi(const KParams& kp, const Lds<OffT>& l
   mp.lds_chain = 0;
   mp.vslo = 1;
   mp.vshi = 0;
+#if AWV_PLAN_PIPELINED
+  // The predicted metadata of the pass's steps, one after the other (step t's I/D rows feed step t + 1 / t + 2), without an LDS
+  // round trip per step: the I/D rows of the last e1 / e2 scores travel in scalar registers (queues like compute_rows_multi's),
+  // and the three M rows a step reads -- x, o1 + e1 and o2 + e2 scores back, all written at least two iterations ago -- are
+  // fetched one iteration ahead by lanes 0..2.  (plan_step did one dependent LDS round trip per score: 15 in a row per pass and
+  // direction, a quarter of a narrow sub-problem's pass.)  All arithmetic on the scalar unit (s_min / s_max / s_add).
+  {
+    typedef typename MetaTraits<OffT>::Stored MetaStored;
+    const int rmask = kp.ring - 1;
+    MetaStored* const meta = lds.ring_meta + (size_t)dir * NCOMP * kp.ring;
+    auto ld_mlags = [&](int score) -> RowMeta {  // lane 0 / 1 / 2: the M row x / o1 + e1 / o2 + e2 scores before `score`
+      const int lag = lane == 0 ? pn.x : lane == 1 ? pn.o1 + pn.e1 : pn.o2 + pn.e2;
+      const int sl = score - lag;
+      RowMeta m = ROW_EMPTY;
+      if (lane < (P2 ? 3 : 2) && sl >= 0) m = meta_load(&meta[C_M * kp.ring + (sl & rmask)]);
+      return m;
+    };
+    // the I/D rows the pass begins with (scores s0 - e + 1 .. s0): lanes 0 .. NS0 - 1 fetch them in one LDS round trip -- the lane
+    // order of multi_source is the queues' -- together with the first step's M rows (lanes 0..2 of a second access)
+    RowMeta q0 = ROW_EMPTY;
+    {
+      int qc, qs;
+      multi_source<P2, E1, E2>(pn, s0, lane, qc, qs);
+      if (lane < NS0 && qs >= 0) q0 = meta_load(&meta[qc * kp.ring + (qs & rmask)]);
+    }
+    RowMeta cur = ld_mlags(s0 + 1);
+    auto hand = [&](int l) { return RowMeta{__builtin_amdgcn_readlane(q0.lo, l), __builtin_amdgcn_readlane(q0.hi, l)}; };
+    RowMeta qI1[E1], qD1[E1], qI2[E2], qD2[E2];
+#pragma unroll
+    for (int j = 0; j < E1; ++j) { qI1[j] = hand(j); qD1[j] = hand(E1 + j); }
+#pragma unroll
+    for (int j = 0; j < E2; ++j) {
+      qI2[j] = P2 ? hand(2 * E1 + j) : ROW_EMPTY;
+      qD2[j] = P2 ? hand(2 * E1 + E2 + j) : ROW_EMPTY;
+    }
+    for (int t = 0; t < Tn; ++t) {
+      const int score = s0 + 1 + t;
+      const RowMeta nxt = ld_mlags(score + 1);  // (in flight while this step's arithmetic runs)
+      const int Mx_lo = __builtin_amdgcn_readlane(cur.lo, 0), Mx_hi = __builtin_amdgcn_readlane(cur.hi, 0);
+      const int O1_lo = __builtin_amdgcn_readlane(cur.lo, 1), O1_hi = __builtin_amdgcn_readlane(cur.hi, 1);
+      int plo[NCOMP], phi[NCOMP];
+      plo[C_I1] = s_add(s_min(O1_lo, qI1[0].lo), 1);
+      phi[C_I1] = s_add(s_max(O1_hi, qI1[0].hi), 1);
+      plo[C_D1] = s_add(s_min(O1_lo, qD1[0].lo), -1);
+      phi[C_D1] = s_add(s_max(O1_hi, qD1[0].hi), -1);
+      plo[C_I2] = plo[C_D2] = K_BIG;
+      phi[C_I2] = phi[C_D2] = -K_BIG;
+      int mlo = s_min(Mx_lo, s_min(plo[C_I1], plo[C_D1])), mhi = s_max(Mx_hi, s_max(phi[C_I1], phi[C_D1]));
+      if (P2) {
+        const int O2_lo = __builtin_amdgcn_readlane(cur.lo, 2), O2_hi = __builtin_amdgcn_readlane(cur.hi, 2);
+        plo[C_I2] = s_add(s_min(O2_lo, qI2[0].lo), 1);
+        phi[C_I2] = s_add(s_max(O2_hi, qI2[0].hi), 1);
+        plo[C_D2] = s_add(s_min(O2_lo, qD2[0].lo), -1);
+        phi[C_D2] = s_add(s_max(O2_hi, qD2[0].hi), -1);
+        mlo = s_min(mlo, s_min(plo[C_I2], plo[C_D2]));
+        mhi = s_max(mhi, s_max(phi[C_I2], phi[C_D2]));
+      }
+      plo[C_M] = mlo;
+      phi[C_M] = mhi;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        meta_store_scalar(&meta[c * kp.ring + (score & rmask)], plo[c], phi[c]);
+        if (BASE && lane == 0) lds.meta_log[score * NCOMP + c] = plo[c] > phi[c] ? ROW_EMPTY : RowMeta{plo[c], phi[c]};  // history for the backtrace
+      }
+      // this score's I/D rows enter the queues (an empty one as {K_BIG, -K_BIG}: it drops out of the next minima / maxima)
+      auto norm = [](int lo, int hi) { return lo > hi ? ROW_EMPTY : RowMeta{lo, hi}; };
+#pragma unroll
+      for (int j = 0; j + 1 < E1; ++j) { qI1[j] = qI1[j + 1]; qD1[j] = qD1[j + 1]; }
+      qI1[E1 - 1] = norm(plo[C_I1], phi[C_I1]);
+      qD1[E1 - 1] = norm(plo[C_D1], phi[C_D1]);
+#pragma unroll
+      for (int j = 0; j + 1 < E2; ++j) { qI2[j] = qI2[j + 1]; qD2[j] = qD2[j + 1]; }
+      qI2[E2 - 1] = norm(plo[C_I2], phi[C_I2]);
+      qD2[E2 - 1] = norm(plo[C_D2], phi[C_D2]);
+      if (lane == t) { mp.vslo = mlo; mp.vshi = mhi; }
+      if (mlo <= mhi) {
+        mp.lo_min = min(mp.lo_min, mlo);
+        mp.hi_max = max(mp.hi_max, mhi);
+      }
+      cur = nxt;
+    }
+  }
+#else
   for (int t = 0; t < Tn; ++t) {  // (uniform) the predicted metadata of step t is in LDS before step t + 1 is planned
     StepPlan pl;
     plan_step<P2, BASE, OffT, true>(kp, lds, dir, s0 + 1 + t, pl);
@@ -1318,6 +1406,7 @@ __device__ __forceinline__ void plan_multi(const KParams& kp, const Lds<OffT>& l
       mp.hi_max = max(mp.hi_max, pl.hi);
     }
   }
+#endif
   // every source row's stored extent = the hull of the step that wrote it (its M row's metadata), fetched by
   // lane r in one LDS round trip.  Score 0 is special -- the search's origin: one cell in the begin
   // component's row, nothing stored for the others -- so there the component's own range counts; rows
@@ -2021,16 +2110,10 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
     // The pass's rows become official.  WFA2's phase-1 order is forward, test, reverse, test per score (A.6), but
     // the running maxima only grow: some test inside the pass holds exactly when the one after its last score
     // does -- so one maximum per direction over the whole pass decides it, and no per-score reduction is
-    // needed.  (The per-score entries written below are that upper bound: the overlap search never looks at a
-    // pass's scores -- they lie before `deep_since` -- and a bound could only make its row filter scan more.)
+    // needed.  (No per-score entries -- bi_A / bi_oob -- are written for a far-apart pass's scores: their only reader, the
+    // overlap search of phase 2, looks at the last `scope` scores of either side, all of which lie at or above `deep_since`
+    // (deep_ok), i.e. past every far-apart pass; a ring slot is rewritten by the deep pass or step that next lands on it.)
     const int P0 = uni(sh.chain_maxak[0][0]), P1 = uni(sh.chain_maxak[1][0]);
-    for (int t = 0; t < T; ++t) {
-      const int slot = (sc + 1 + t) & rmask;
-      lds.bi_A[slot] = P0;
-      lds.bi_A[kp.ring + slot] = P1;
-      lds.bi_oob[slot] = 0;
-      lds.bi_oob[kp.ring + slot] = 0;
-    }
     arun0 = max(arun0, P0);
     arun1 = max(arun1, P1);
     fmax = max(fmax, P0);
