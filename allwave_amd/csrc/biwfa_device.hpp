@@ -16,11 +16,16 @@
 //     direction), row metadata (lo/hi, max antidiagonal) in LDS;
 //   * while the two searches are far apart a window advances 5 scores per pass (15 with chained sweeps
 //     under the default scores) with the I/D rows -- and the previous sweeps' M rows -- in registers
-//     (compute_rows_multi); near the meeting point and in trimmed rows every score is a step of its
-//     own (compute_row), forward and reverse steps fused, one workgroup barrier per step;
-//   * the far-apart phase (multi_phase), the base case's passes (base_phase), the breakpoint search
-//     (find_breakpoint_fn) and the trimmed-hull search (trim_pass_fn) are real functions with register
-//     files of their own; their inputs travel through LDS (Shared::pctx).
+//     (compute_rows_multi; the chain registers double as the first sweep's load targets, the next sweep's
+//     remaining source rows are loaded a sweep ahead); from the safety margin before the meeting point on,
+//     passes of 5 scores that also store every I/D row (deep_phase), until phase 1 of the search ends; phase 2
+//     and trimmed rows go score by score (compute_row), forward and reverse steps fused, one barrier per step;
+//   * long sequences (32-bit rows): three chained sweeps with the middle sweep's rows in LDS wherever the
+//     sub-problem is too long for its packed sequences to be staged there;
+//   * the far-apart phase (multi_phase, which tail-calls deep_phase), the base case's passes (base_phase), the
+//     breakpoint search (find_breakpoint_fn) and the trimmed-hull search (trim_pass_fn) are real functions with
+//     register files of their own; their inputs travel through LDS (Shared::pctx); the passes' planning
+//     (plan_multi) runs on the scalar unit without an LDS round trip per score.
 //
 //   * rows are 16-bit whenever every stored value fits: text offsets when both sequences are shorter than
 //     32760, min(h, v) per cell when only the shorter one is (AWV_WIDE16: 32-bit row metadata); 32-bit rows
@@ -274,7 +279,7 @@ struct SubCtx {
   int kmin[2];
   int wcols;
   // 2-bit packed staging in LDS (only when both sequences are pure upper-case ACGT and the words fit)
-  int seq_mode;            // 0: probes read raw bytes from global memory, 1: packed words staged in LDS
+  int seq_mode;            // 0: probes read raw bytes from global memory, 1: packed words staged in LDS, 2: packed words read from global memory (P[0] / T[0] point at them)
   int p_w0, t_w0;          // first staged word of pattern / text in Lds::seq (2 pad words before, 3 after)
   int p_bit, t_bit;        // position (0..15) of the sub-problem's first base inside that word
   gwords_t Pw, Tw;         // the whole sequences' packed words in HBM (nullptr: not packable)
@@ -489,6 +494,10 @@ __device__ __forceinline__ int packed_first_count(const uint32_t* seq, const Sub
 // series, about 40 % of a wave's step time.  Here the reads of NB cells (2 NB ds_read2_b32) go out back to back and are
 // waited for once.  (Inline asm: the compiler places no waits around what it cannot see, so the wait is part of the block;
 // it also drains whatever LDS / scalar-memory operation of the compiler's own was in flight, which is harmless.)
+// sub-problems whose lengths add up to no more than this run step by step throughout (a pass function's call + planning do not pay)
+#ifndef AWV_MIN_PASS_LEN
+#define AWV_MIN_PASS_LEN 1024
+#endif
 // 1: plan_multi plans a pass's steps without an LDS round trip per step (I/D metadata forwarded in scalar registers, M rows
 // fetched an iteration ahead); 0: one plan_step per score
 #ifndef AWV_PLAN_PIPELINED
@@ -581,8 +590,74 @@ __device__ __forceinline__ int extend_lcp_packed(const uint32_t* seq, const SubC
   return min(n, rem);
 }
 
+// ---- seq_mode 2 (round 3): a sub-problem too long to be staged probes the SAME 2-bit words where they lie in HBM instead of
+// the raw bytes.  A 100 kbp pair's two sequences are 50 KB that way instead of 200 KB, and a 64-byte line holds 256 bases: a
+// step's probes -- one pair of positions per diagonal, neighbouring diagonals a few bases apart -- touch a quarter of the
+// lines, and the 128 pairs an XCD has in flight fit its 4 MB L2 four times better.  SubCtx::P[0] / T[0] then point at the word
+// holding the sub-problem's first base (p_bit / t_bit = its position in that word, as in LDS); the raw pointers are not kept.
+// The engine pads the packed arrays with two words in front (reverse probes of a sequence's first bases read up to two words
+// below its first) and four behind; what a probe reads outside the sub-problem is cut off by the remaining length.
+#ifndef AWV_GLOBAL_PACKED
+#define AWV_GLOBAL_PACKED 1
+#endif
+typedef unsigned int u32x3_t __attribute__((ext_vector_type(3)));
+typedef u32x2_t __attribute__((aligned(4))) u32x2_a4;
+typedef u32x3_t __attribute__((aligned(4))) u32x3_a4;
+__device__ __forceinline__ u32x2_t gw_load2(gseq_t base, int pos) {
+  return *(const __attribute__((address_space(1))) u32x2_a4*)(base + (unsigned)((pos >> 4) << 2));
+}
+__device__ __forceinline__ uint64_t gw_bits64(gseq_t base, int pos) {
+  const u32x3_t w = *(const __attribute__((address_space(1))) u32x3_a4*)(base + (unsigned)((pos >> 4) << 2));
+  const unsigned sh = ((unsigned)pos & 15u) * 2u;
+  return ((uint64_t)__builtin_amdgcn_alignbit(w.z, w.y, sh) << 32) | __builtin_amdgcn_alignbit(w.y, w.x, sh);
+}
+// word bases and bit offsets of the probes of direction DIR (reverse: the bases that END at forward position len - v, one pad
+// word back for the 16-base probe, two for the 32-base one)
+template <int DIR, int BACK>
+__device__ __forceinline__ void gw_frame(const SubCtx& cx, gseq_t& bP, gseq_t& bT, int& oP, int& oT) {
+  bP = cx.P[0] - (DIR ? 4 * BACK : 0);
+  bT = cx.T[0] - (DIR ? 4 * BACK : 0);
+  oP = DIR ? cx.p_bit + cx.plen : cx.p_bit;
+  oT = DIR ? cx.t_bit + cx.tlen : cx.t_bit;
+}
+template <int DIR>
+__device__ __forceinline__ void gw_first_counts4(const SubCtx& cx, const int (&vv)[4], const int (&hh)[4], int (&nn)[4]) {
+  gseq_t bP, bT;
+  int oP, oT;
+  gw_frame<DIR, 1>(cx, bP, bT, oP, oT);
+  u32x2_t wP[4], wT[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {  // eight loads in flight, one wait
+    wP[j] = gw_load2(bP, DIR ? oP - vv[j] : oP + vv[j]);
+    wT[j] = gw_load2(bT, DIR ? oT - hh[j] : oT + hh[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned sP = (unsigned)(DIR ? oP - vv[j] : oP + vv[j]) << 1, sT = (unsigned)(DIR ? oT - hh[j] : oT + hh[j]) << 1;
+    const unsigned x = __builtin_amdgcn_alignbit(wP[j].y, wP[j].x, sP) ^ __builtin_amdgcn_alignbit(wT[j].y, wT[j].x, sT);
+    nn[j] = DIR == 0 ? ((x ? __builtin_ctz(x) : 32) >> 1) : ((x ? __builtin_clz(x) : 32) >> 1);
+  }
+}
+template <int DIR>
+__device__ __forceinline__ int extend_lcp_gw(const SubCtx& cx, int v, int h, unsigned& iters) {
+  gseq_t bP, bT;
+  int oP, oT;
+  gw_frame<DIR, 2>(cx, bP, bT, oP, oT);
+  const int rem = min(cx.plen - v, cx.tlen - h);
+  int n = 0;
+  while (n < rem) {
+    const uint64_t x = gw_bits64(bP, DIR ? oP - v - n : oP + v + n) ^ gw_bits64(bT, DIR ? oT - h - n : oT + h + n);
+    ++iters;
+    const int c = packed_count<DIR>(x);
+    n += c;
+    if (c < PROBE_PACKED) break;
+  }
+  return min(n, rem);
+}
+
 // Copies the sub-problem's packed words into LDS (all threads; ends with a barrier).  Falls back
-// to raw-byte probes from global memory when the pair is not packable or the words do not fit.
+// to probes from global memory -- of the packed words (seq_mode 2) when the pair is packable and the words do not fit, of the
+// raw bytes when it is not packable.
 template <typename OffT>
 __device__ __forceinline__ void stage_sequences(const KParams& kp, const Lds<OffT>& lds, SubCtx& cx) {
   cx.seq_mode = 0;
@@ -595,7 +670,14 @@ __device__ __forceinline__ void stage_sequences(const KParams& kp, const Lds<Off
   cx.p_w0 = 2;
   cx.t_w0 = cx.p_w0 + npw + 3 + 2;
   const int total_words = cx.t_w0 + ntw + 3;
-  if (total_words * 4 > kp.lds_seq_bytes) return;
+  if (total_words * 4 > kp.lds_seq_bytes) {
+    if (AWV_GLOBAL_PACKED) {
+      cx.seq_mode = 2;
+      cx.P[0] = cx.P[1] = (gseq_t)(cx.Pw + pw_first);
+      cx.T[0] = cx.T[1] = (gseq_t)(cx.Tw + tw_first);
+    }
+    return;
+  }
   cx.seq_mode = 1;
   const int t0 = cold_tid();
   for (int i = t0; i < npw; i += WG) lds.seq[cx.p_w0 + i] = cx.Pw[pw_first + i];
@@ -781,7 +863,7 @@ __device__ __forceinline__ void extend_cells_n(const Lds<OffT>& lds, const SubCt
   const gseq_t Tp = dir ? cx.T[1] : cx.T[0];
   const int plen = cx.plen, tlen = cx.tlen;
   int rr[N], vv[N], hh[N];
-  const bool packed = cx.seq_mode != 0;
+  const bool packed = cx.seq_mode == 1, gpacked = cx.seq_mode == 2;
   const uint32_t* seq = lds.seq;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -826,6 +908,20 @@ __device__ __forceinline__ void extend_cells_n(const Lds<OffT>& lds, const SubCt
       cont |= (nn[j] == PROBE_FIRST && rr[j] > PROBE_FIRST) ? (1u << j) : 0u;
       m[j] += min(nn[j], rr[j]);  // rr == 0 for NULL cells: unchanged
     }
+  } else if (gpacked) {
+#pragma unroll
+    for (int g = 0; g < N; g += 4) {
+      int v4[4], h4[4], n4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v4[j] = vv[g + j]; h4[j] = hh[g + j]; }
+      if (dir == 0) gw_first_counts4<0>(cx, v4, h4, n4);
+      else gw_first_counts4<1>(cx, v4, h4, n4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        cont |= (n4[j] == PROBE_FIRST && rr[g + j] > PROBE_FIRST) ? (1u << (g + j)) : 0u;
+        m[g + j] += min(n4[j], rr[g + j]);
+      }
+    }
   } else {
     uint64_t xx[N];
 #pragma unroll
@@ -845,6 +941,7 @@ __device__ __forceinline__ void extend_cells_n(const Lds<OffT>& lds, const SubCt
         const int v = wenc_of<OffT>() ? m[j] + max(-(k0 + (j & 3)), 0) : m[j] - (k0 + (j & 3));
         const int h = wenc_of<OffT>() ? m[j] + max(k0 + (j & 3), 0) : m[j];
         if (packed) m[j] += dir == 0 ? extend_lcp_packed<0>(seq, cx, v, h, ext_iters) : extend_lcp_packed<1>(seq, cx, v, h, ext_iters);
+        else if (gpacked) m[j] += dir == 0 ? extend_lcp_gw<0>(cx, v, h, ext_iters) : extend_lcp_gw<1>(cx, v, h, ext_iters);
         else m[j] += extend_lcp(Pp, Tp, v, h, plen, tlen, ext_iters);
       }
     }
@@ -899,7 +996,7 @@ __device__ __forceinline__ void extend_cells_lean(const Lds<OffT>& lds, const Su
   };
 #pragma unroll
   for (int j = 0; j < 4; ++j) rr[j] = hmaxv[j] - cand[j];
-  if (cx.seq_mode != 0) {
+  if (cx.seq_mode == 1) {
     positions(AWV_OOB_PROBES != 0);
     if constexpr (NBATCH != 0) {
       if (dir == 0) packed_first_counts4<0, NBATCH ? NBATCH : 4>(seq, cx, vv, hh, nn);
@@ -926,8 +1023,26 @@ __device__ __forceinline__ void extend_cells_lean(const Lds<OffT>& lds, const Su
     }
     return;
   }
-  // raw-byte probes from global memory (sequences that are not pure upper-case ACGT, or too long for the LDS staging)
   positions(false);
+  if (cx.seq_mode == 2) {  // packed words from global memory (too long for the LDS staging)
+    if (dir == 0) gw_first_counts4<0>(cx, vv, hh, nn);
+    else gw_first_counts4<1>(cx, vv, hh, nn);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = min(nn[j], rr[j]);
+      const bool more = ok[j] && t == PROBE_FIRST;
+      int mo = cand[j] + t;
+      if (more) {
+        const int k = k0 + j;
+        const int v = wenc_of<OffT>() ? mo + max(-k, 0) : mo - k;
+        const int h = wenc_of<OffT>() ? mo + max(k, 0) : mo;
+        mo += dir == 0 ? extend_lcp_gw<0>(cx, v, h, ext_iters) : extend_lcp_gw<1>(cx, v, h, ext_iters);
+      }
+      m[j] = ok[j] ? mo : OFF_NULL;
+    }
+    return;
+  }
+  // raw-byte probes from global memory (sequences that are not pure upper-case ACGT)
   const gseq_t Pp = dir ? cx.P[1] : cx.P[0];
   const gseq_t Tp = dir ? cx.T[1] : cx.T[0];
   uint64_t xx[4];
@@ -2070,7 +2185,7 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
   unsigned long long cells = 0;
   unsigned ext_iters = 0;
   // 32-bit rows: a third chained sweep when the staging region of the packed sequences can hold the chain rows (AWV_LDS_CHAIN)
-  const bool lds_chain = CHAIN && sizeof(OffT) == 4 && (AWV_LDS_CHAIN != 0) && cx.seq_mode == 0 &&
+  const bool lds_chain = CHAIN && sizeof(OffT) == 4 && (AWV_LDS_CHAIN != 0) && cx.seq_mode != 1 &&
                          uni(pc.lds_seq_bytes) >= (WG / 64) * TMAX32 * 64 * 16;
   const int chain_cap = CHAIN ? min(max(uni(pc.chain_max), 1), sizeof(OffT) == 2 ? CHAIN_MAX : (lds_chain ? 3 : CHAIN_MAX32)) : 1;
   for (;;) {
@@ -2563,7 +2678,7 @@ __device__ __forceinline__ int base_align(const KParams& kp, Shared& sh, const L
   if (tid == 0) {
     unsigned it = 0;
     int v0 = 0;
-    if (cb == C_M) v0 = extend_lcp(cx.P[0], cx.T[0], 0, 0, plen, tlen, it);
+    if (cb == C_M) v0 = cx.seq_mode == 2 ? extend_lcp_gw<0>(cx, 0, 0, it) : extend_lcp(cx.P[0], cx.T[0], 0, 0, plen, tlen, it);
     for (int j = 0; j < 4; ++j) hist[(size_t)cb * kp.wb_cap + (((0 - kmin) & ~3) + j)] = (OffT)(sizeof(OffT) == 2 ? NULL16 : OFF_NULL);
     hist[(size_t)cb * kp.wb_cap + (0 - kmin)] = (OffT)v0;  // the score-0 row: one cell in a whole lane vector
     acc_reset(sh.acc[0][0]);
@@ -3038,7 +3153,9 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
     const int begin = dir == 0 ? cb : ce;
     unsigned it = 0;
     int v0 = 0;
-    if (begin == C_M) v0 = extend_lcp(dir ? cx.P[1] : cx.P[0], dir ? cx.T[1] : cx.T[0], 0, 0, plen, tlen, it);
+    if (begin == C_M)
+      v0 = cx.seq_mode == 2 ? (dir ? extend_lcp_gw<1>(cx, 0, 0, it) : extend_lcp_gw<0>(cx, 0, 0, it))
+                            : extend_lcp(dir ? cx.P[1] : cx.P[0], dir ? cx.T[1] : cx.T[0], 0, 0, plen, tlen, it);
     {  // the score-0 row: one cell, stored as a whole lane vector like every other row
       const int col = 0 - (dir ? cx.kmin[1] : cx.kmin[0]);
       OffT* row = row_ptr<false, OffT>(kp, ring_mem, dir, begin, 0);
@@ -3079,7 +3196,7 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
   // Multi-step passes (compute_rows_multi) while the searches are far apart; step by step -- every I/D
   // row kept, as the overlap search needs them -- from a safe margin before they can meet.
   constexpr bool MULTI_BUILD = !DIRSPLIT;
-  const int multi_T = (MULTI_BUILD && !force_single && plen + tlen > 1024) ? kp.multi_T : 0;  // 0: step by step throughout
+  const int multi_T = (MULTI_BUILD && !force_single && plen + tlen > AWV_MIN_PASS_LEN) ? kp.multi_T : 0;  // 0: step by step throughout
   bool deep_on = multi_T == 0;     // every step stores its I/D rows
   int deep_since[2] = {deep_on ? 0 : INT_MAX, deep_on ? 0 : INT_MAX};  // first score from which all I/D rows are in HBM
   // the overlap search of (d0, s0) against d1 reads the I/D rows of s0 and of scores s1 - scope + 1 .. s1

@@ -199,7 +199,9 @@ int upload_seqset(awv_engine* e, SeqSet& s, int32_t n, const uint8_t* bytes, con
   }
   // 2-bit packed copies (A,C,G,T -> 0..3, 16 bases per word) for sequences made of upper-case ACGT only;
   // bytes are compared verbatim by the reference, so anything else keeps the raw-byte path
-  std::vector<uint64_t> off2((size_t)n + 1, 0);
+  // (two pad words in front of the first sequence, one behind every sequence and four at the end: the kernels' probes of
+  // packed words in place -- seq_mode 2 -- read up to two words below a sequence's first and two beyond its last)
+  std::vector<uint64_t> off2((size_t)n + 1, 2);
   std::vector<uint8_t> ok2((size_t)std::max(n, 1), 0);
   for (int i = 0; i < n; ++i) off2[i + 1] = off2[i] + ((size_t)s.len[i] + 15) / 16 + 1;
   std::vector<uint32_t> h2[2];

@@ -299,9 +299,20 @@ def test_multi_step_passes_all_presets(oracle, scores):
         check_against_oracle(e, oracle, seqs, pairs, scores)
         st = e.stats()
         assert st.multi_cell_steps > 0.3 * st.cell_steps, (st.multi_cell_steps, st.cell_steps)
+        assert st.deep_cell_steps > 0, "the margin zone ran in passes that store every I/D row (deep_phase)"
         res_multi, cig_multi = e.align_pairs(scores, pairs)
     finally:
         e.close()
+    # the round-2 path: far-apart passes only, the margin zone step by step
+    e = ffi.Engine(flags=ffi.AWV_F_ONE_WAVE | ffi.AWV_F_NO_DEEP)
+    try:
+        e.set_sequences(seqs)
+        res_nodeep, cig_nodeep = e.align_pairs(scores, pairs)
+        st = e.stats()
+        assert st.deep_cell_steps == 0 and st.multi_cell_steps > 0.2 * st.cell_steps
+    finally:
+        e.close()
+    assert (res_multi["penalty"] == res_nodeep["penalty"]).all() and cig_multi == cig_nodeep
     e = ffi.Engine(flags=ffi.AWV_F_ONE_WAVE | ffi.AWV_F_SINGLE_STEP)
     try:
         e.set_sequences(seqs)
@@ -361,6 +372,48 @@ def test_unstaged_long_pairs_chain_through_lds(oracle):
         finally:
             e.close()
     assert out[0] == out[1]
+
+
+def test_packed_probes_of_unstaged_sub_problems(oracle):
+    """Sub-problems too long for the LDS staging probe the 2-bit words where they lie in HBM (seq_mode 2, biwfa_device.hpp):
+    forward and reverse probes, sub-problems that begin inside a word and inside the sequence (the second BiWFA level of a
+    150 kbp pair is still unstaged), a sequence's very first and last bases (the first sequence of the set: the pad words in
+    front of the packed array), reverse-complemented queries, one wave per pair (a 6 KB staging region: 20 kbp pairs are
+    unstaged there) and four, 16- and 32-bit rows -- against the oracle and against the raw-byte probes (AWV_F_NO_PACKED_SEQ).
+    A pair with a non-ACGT base keeps the raw bytes."""
+    from allwave_amd import ffi
+    rng = random.Random(777)
+    comp = {65: 84, 84: 65, 67: 71, 71: 67}
+
+    def rc(s):
+        return bytes(comp.get(b, 78) for b in reversed(s))
+
+    a = rand_seq(rng, 150000)
+    b = mutate(a, 0.015, rng)
+    c = rand_seq(rng, 20000)
+    d = mutate(c, 0.06, rng)
+    f = mutate(c, 0.04, rng)
+    n = bytearray(mutate(c, 0.03, rng))
+    n[7000] = ord("N")
+    seqs = [a, b, c, d, rc(f), bytes(n)]
+    long_pairs = [(0, 1, 0), (1, 0, 0)]
+    short_pairs = [(2, 3, 0), (3, 2, 0), (4, 2, 1), (4, 3, 1), (5, 2, 0), (2, 5, 0)]
+    al = oracle.Aligner(DEFAULT_2P)
+    plain = {4: f}
+    want = {}
+    for p in long_pairs + short_pairs:
+        want[p] = al.align(plain.get(p[0], seqs[p[0]]), seqs[p[1]])
+    for flags, pairs in ((0, long_pairs + short_pairs), (ffi.AWV_F_ONE_WAVE, short_pairs), (ffi.AWV_F_ONE_WAVE | ffi.AWV_F_FORCE_INT32, short_pairs),
+                         (ffi.AWV_F_FOUR_WAVES | ffi.AWV_F_NO_PACKED_SEQ, long_pairs[:1] + short_pairs)):
+        e = ffi.Engine(flags=flags)
+        try:
+            e.set_sequences(seqs)
+            res, cigs = e.align_pairs(DEFAULT_2P, pairs)
+            for i, p in enumerate(pairs):
+                assert res["status"][i] == 0, (flags, p)
+                assert (res["penalty"][i], cigs[i]) == want[p], (flags, p, res["penalty"][i], want[p][0])
+        finally:
+            e.close()
 
 
 def test_narrow_first_attempt_is_rerun_with_wider_rows(oracle):
