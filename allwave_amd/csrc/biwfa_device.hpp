@@ -78,6 +78,11 @@ enum { C_M = 0, C_I1 = 1, C_I2 = 2, C_D1 = 3, C_D2 = 4 };
 constexpr int FALLBACK_MIN_SCORE = 250;
 constexpr int FALLBACK_MIN_LENGTH = 100;
 constexpr int STACK_CAP = 48;
+// 1: inside a launch with 32-bit rows, sub-problems of which both lengths are below SUB16_MAX_LEN are searched with 16-bit rows
+#ifndef AWV_SUB16
+#define AWV_SUB16 1
+#endif
+constexpr int SUB16_MAX_LEN = 32760;  // (the engine's own limit for 16-bit rows: engine.hip)
 // Occupancy target: waves per SIMD (the register budget the kernel is compiled for) and the static
 // LDS the kernel declares; the engine sizes the dynamic LDS so that WAVES_PER_SIMD * 4 waves fit a CU.
 #ifndef AWV_WAVES_PER_SIMD
@@ -143,6 +148,7 @@ struct KParams {
   int chain_max;   // sweeps a multi-step pass may chain (1: none; > 1 needs x == TMAX and o1 + e1 == 2 TMAX, ring >= scope + 2 + TMAX * chain_max - 1)
   int multi_T;     // steps per multi-step pass (0: off): <= min(TMAX, x, o1+e1, o2+e2, ring - scope - 1), e1/e2 among the instantiated depths
   int deep_passes; // 1: the margin zone of phase 1 runs in passes that store every I/D row (deep_phase); 0: step by step there (round 2)
+  int sub16;       // 32-bit launches: 1 = sub-problems whose lengths fit 16-bit rows are searched with 16-bit rows (AWV_SUB16)
   int wcap;        // columns per ring row
   void* ring_mem;
   size_t ring_slot_stride;  // bytes per workgroup slot
@@ -2123,6 +2129,10 @@ __device__ __attribute__((noinline)) void deep_phase(unsigned sh_addr, unsigned 
 // safety margin = BASE + MUL4/4 * (scope + T) * (recent advance per step), in antidiagonal units.  Tuned on config 2
 // (profiles/r02/margin_ab.json): 256 + 2.0 x -> 1926 ms, 26 restarts; 256 + 1.5 x -> 1903 ms, 942 restarts of 979 k searches;
 // 128 + 1.5 x -> 1911 ms, 13 k restarts; 64 + 1.25 x -> 2154 ms, 124 k restarts.
+// attempts of a breakpoint search: 3 = the margins below, four times the margins, step by step; 2 = round 2's rule (step by step at once)
+#ifndef AWV_RESTART_ATTEMPTS
+#define AWV_RESTART_ATTEMPTS 3
+#endif
 #ifndef AWV_MARGIN_BASE
 #define AWV_MARGIN_BASE 256
 #endif
@@ -2187,6 +2197,8 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
   // 32-bit rows: a third chained sweep when the staging region of the packed sequences can hold the chain rows (AWV_LDS_CHAIN)
   const bool lds_chain = CHAIN && sizeof(OffT) == 4 && (AWV_LDS_CHAIN != 0) && cx.seq_mode != 1 &&
                          uni(pc.lds_seq_bytes) >= (WG / 64) * TMAX32 * 64 * 16;
+  const int margin_shift = (uni(deep_v) >> 8) & 3;  // a restarted search: the margin times four (find_breakpoint)
+  const bool long_reads = (uni(deep_v) & 0x400) != 0;  // a 16-bit search of a launch with 32-bit rows: those reads' margin factor
   const int chain_cap = CHAIN ? min(max(uni(pc.chain_max), 1), sizeof(OffT) == 2 ? CHAIN_MAX : (lds_chain ? 3 : CHAIN_MAX32)) : 1;
   for (;;) {
     // Start keeping every I/D row well before the furthest points can meet: the margin is several times what
@@ -2198,8 +2210,8 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
       const int T = c > 1 ? TMAX * c : Tn;
       // (32-bit rows = long sequences with long exact runs: the searches advance in larger bursts, 2.0 x instead of 1.5 x -- config 4:
       // 9.91 s and 4.9 k restarted searches against 10.31 s and 26 k)
-      const int mul4 = sizeof(OffT) == 2 ? MARGIN_MUL4 : MARGIN_MUL4 + 2;
-      if (arun0 + arun1 < max_antidiagonal - (MARGIN_BASE + mul4 * (kp.pen.scope + T) * max(grow, 8) / 4)) { nh = c; break; }
+      const int mul4 = (sizeof(OffT) == 2 && !long_reads) ? MARGIN_MUL4 : MARGIN_MUL4 + 2;
+      if (arun0 + arun1 < max_antidiagonal - ((MARGIN_BASE + mul4 * (kp.pen.scope + T) * max(grow, 8) / 4) << margin_shift)) { nh = c; break; }
     }
     if (nh == 0) { why = MP_MARGIN; break; }
     const int T = nh > 1 ? TMAX * nh : Tn;
@@ -2266,7 +2278,7 @@ __device__ __attribute__((noinline)) void multi_phase(unsigned sh_addr, unsigned
   // The margin is reached: the rest of phase 1 runs in passes that store every I/D row (deep_phase), called from HERE -- a call
   // site of its own in find_breakpoint_fn cost that function's step-by-step loop register spills (config 5's forced-gap pairs,
   // which live in that loop: +24 %); its result record replaces the one above and carries the far-apart passes' counts along.
-  if (uni(deep_v) != 0 && why == MP_MARGIN)
+  if ((uni(deep_v) & 1) != 0 && why == MP_MARGIN)
     deep_phase<P2, OffT, E1, E2>(sh_addr, dyn_addr, sc, fmax, rmax, Tn, pass, npass, (unsigned)cells, (unsigned)(cells >> 32));
 }
 
@@ -3100,7 +3112,7 @@ __device__ __forceinline__ void bialign_overlap(const KParams& kp, Shared& sh, c
 
 template <bool P2, typename OffT>
 __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, const Lds<OffT>& lds, SubCtx cx, void* ring_mem, rsrc_t ring_rs, int cb, int ce,
-                               int score_remaining, int known_score, bool force_single, Breakpoint& bp, unsigned long long* lstats) {
+                               int score_remaining, int known_score, int attempt, Breakpoint& bp, unsigned long long* lstats) {
   const DevPenalties& pn = kp.pen;
   const int tid = cold_tid();
   const int plen = cx.plen, tlen = cx.tlen;
@@ -3196,6 +3208,11 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
   // Multi-step passes (compute_rows_multi) while the searches are far apart; step by step -- every I/D
   // row kept, as the overlap search needs them -- from a safe margin before they can meet.
   constexpr bool MULTI_BUILD = !DIRSPLIT;
+  // attempt 0: the margins of multi_phase; 1 (the furthest points met inside a far-apart pass): once more with four times the
+  // margin; 2 (again): step by step throughout
+  const bool force_single = (attempt & 0xff) >= AWV_RESTART_ATTEMPTS - 1;
+  // (bits 8, 9 = log2 of the margin's multiplier, bit 10 = the margin factor of long reads although the rows are 16-bit)
+  const int deep_arg = kp.deep_passes | ((attempt & 0xff) == 1 && !force_single ? 0x200 : 0) | ((attempt & 0x100) ? 0x400 : 0);
   const int multi_T = (MULTI_BUILD && !force_single && plen + tlen > AWV_MIN_PASS_LEN) ? kp.multi_T : 0;  // 0: step by step throughout
   bool deep_on = multi_T == 0;     // every step stores its I/D rows
   int deep_since[2] = {deep_on ? 0 : INT_MAX, deep_on ? 0 : INT_MAX};  // first score from which all I/D rows are in HBM
@@ -3224,9 +3241,9 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
         // ---- the far-apart phase: all multi-step passes of this search in one call (multi_phase)
         if constexpr (MULTI_BUILD) {
           // (chained sweeps only where the scores allow them: 2-piece with x = TMAX and o1 + e1 = 2 TMAX, the default set)
-          if (P2) multi_phase<P2, OffT, 2, 1, P2>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass, kp.deep_passes);
-          else if (pn.e1 == 1) multi_phase<P2, OffT, 1, 1, false>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass, kp.deep_passes);
-          else multi_phase<P2, OffT, 2, 1, false>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass, kp.deep_passes);
+          if (P2) multi_phase<P2, OffT, 2, 1, P2>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass, deep_arg);
+          else if (pn.e1 == 1) multi_phase<P2, OffT, 1, 1, false>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass, deep_arg);
+          else multi_phase<P2, OffT, 2, 1, false>(sh_addr, dyn_addr, sc[0], fmax, rmax, multi_T, pass, deep_arg);
         }
         PROF_ADD(STAT_T_BI_COMPUTE, tp0);
         const int why = uni(sh.pres.why);
@@ -3361,12 +3378,12 @@ __device__ __forceinline__ int find_breakpoint(const KParams& kp, Shared& sh, co
 // kernel for the running sub-problem; the breakpoint goes back through Shared::bp_out.
 template <bool P2, typename OffT>
 __device__ __attribute__((noinline)) int find_breakpoint_fn(unsigned sh_addr, unsigned dyn_addr, unsigned lstats_addr, int cb_v, int ce_v,
-                                                            int score_remaining_v, int known_v, int force_single_v) {
+                                                            int score_remaining_v, int known_v, int attempt_v) {
   Shared& sh = *(Shared*)__builtin_assume_aligned((Shared*)(__attribute__((address_space(3))) Shared*)(uintptr_t)uni((int)sh_addr), 8);
   unsigned char* dyn_smem = (unsigned char*)__builtin_assume_aligned((unsigned char*)(__attribute__((address_space(3))) unsigned char*)(uintptr_t)uni((int)dyn_addr), 16);
   unsigned long long* lstats = (unsigned long long*)__builtin_assume_aligned((unsigned long long*)(__attribute__((address_space(3))) unsigned long long*)(uintptr_t)uni((int)lstats_addr), 8);
   const int cb = uni(cb_v), ce = uni(ce_v), score_remaining = uni(score_remaining_v), known = uni(known_v);
-  const bool force_single = uni(force_single_v) != 0;
+  const int attempt = uni(attempt_v);  // bits 0..7: the attempt, bit 8: a 16-bit search inside a launch with 32-bit rows
   const PassCtx& pc = sh.pctx;
   auto uni64 = [](unsigned long long v) { return ((unsigned long long)(unsigned)uni((int)(v >> 32)) << 32) | (unsigned)uni((int)v); };
   KParams kp{};
@@ -3415,7 +3432,7 @@ __device__ __attribute__((noinline)) int find_breakpoint_fn(unsigned sh_addr, un
   const rsrc_t ring_rs = make_rsrc(ring_mem, kp.ring_slot_stride);
   __syncthreads();  // everyone has read pctx before the search rewrites parts of it
   Breakpoint bp;
-  const int rc = find_breakpoint<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, cb, ce, score_remaining, known, force_single, bp, lstats);
+  const int rc = find_breakpoint<P2, OffT>(kp, sh, lds, cx, ring_mem, ring_rs, cb, ce, score_remaining, known, attempt, bp, lstats);
   if (threadIdx.x == 0) sh.bp_out = bp;
   __syncthreads();
   return rc;
@@ -3527,8 +3544,8 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
       Breakpoint bp;
       if (!do_base) {
         int rc = BP_OK;
-        for (int attempt = 0; attempt < 2; ++attempt) {  // (one call site: the search stays inlined)
-          // second attempt: the searches met before the I/D history was being kept -- once more, step by step from the start
+        for (int attempt = 0; attempt < AWV_RESTART_ATTEMPTS; ++attempt) {  // (one call site: the search stays inlined)
+          // later attempts: the searches met before the I/D history was being kept -- once more with a wider margin, then step by step
           if (tid == 0) {  // the search's inputs (find_breakpoint_fn reads them back after a barrier)
             PassCtx& pc = sh.pctx;
             pc.ring_mem = (unsigned long long)(uintptr_t)ring_mem;
@@ -3552,8 +3569,20 @@ __global__ __launch_bounds__(WG, WAVES_PER_SIMD) void biwfa_align_kernel(KParams
             pc.pb_abs = cx.pb_abs; pc.tb_abs = cx.tb_abs;
           }
           __syncthreads();
-          rc = uni(find_breakpoint_fn<P2, OffT>((unsigned)(uintptr_t)&sh, (unsigned)(uintptr_t)lds.ring_meta, (unsigned)(uintptr_t)lstats,
-                                                t.cb, t.ce, t.score_remaining, t.known, attempt == 1 ? 1 : 0));
+          // A launch with 32-bit rows searches the sub-problems that have become short enough with 16-bit rows (AWV_SUB16): the
+          // same ring arena at half the bytes per row, packed arithmetic, the 16-bit metadata layout inside the same LDS region --
+          // a search leaves nothing behind but its breakpoint.  (The base case stays with the launch's row width.)
+          if constexpr (AWV_SUB16 && sizeof(OffT) == 4 && !WENC) {
+            if (kp.sub16 != 0 && max(plen, tlen) < SUB16_MAX_LEN)
+              rc = uni(find_breakpoint_fn<P2, int16_t>((unsigned)(uintptr_t)&sh, (unsigned)(uintptr_t)lds.ring_meta, (unsigned)(uintptr_t)lstats,
+                                                       t.cb, t.ce, t.score_remaining, t.known, attempt | 0x100));  // (0x100: the long reads' margin)
+            else
+              rc = uni(find_breakpoint_fn<P2, OffT>((unsigned)(uintptr_t)&sh, (unsigned)(uintptr_t)lds.ring_meta, (unsigned)(uintptr_t)lstats,
+                                                    t.cb, t.ce, t.score_remaining, t.known, attempt));
+          } else {
+            rc = uni(find_breakpoint_fn<P2, OffT>((unsigned)(uintptr_t)&sh, (unsigned)(uintptr_t)lds.ring_meta, (unsigned)(uintptr_t)lstats,
+                                                  t.cb, t.ce, t.score_remaining, t.known, attempt));
+          }
           if (rc == BP_OK) {
             bp.score = uni(sh.bp_out.score); bp.sf = uni(sh.bp_out.sf); bp.sr = uni(sh.bp_out.sr); bp.kf = uni(sh.bp_out.kf);
             bp.kr = uni(sh.bp_out.kr); bp.off_f = uni(sh.bp_out.off_f); bp.off_r = uni(sh.bp_out.off_r); bp.comp = uni(sh.bp_out.comp);

@@ -592,6 +592,7 @@ int align_core(awv_engine* e, SeqSet& s, const awv_penalties* pen, const awv_pai
       // 32-bit rows: sweeps of at most TMAX32 scores, at most CHAIN_MAX32 of them chained (a lane vector is four registers)
       kp.multi_T = narrow ? multi_T : (std::min(multi_T, awv::TMAX32) >= 2 ? std::min(multi_T, awv::TMAX32) : 0);
       kp.deep_passes = (kp.multi_T > 0 && !(e->cfg.flags & AWV_F_NO_DEEP)) ? 1 : 0;
+      kp.sub16 = (e->cfg.flags & AWV_F_FORCE_INT32) ? 0 : 1;  // (the pin means 32-bit rows throughout)
       // (32-bit rows: two sweeps chained through registers, a third when the kernel finds room for its chain rows in LDS -- the
       // kernel caps what it is offered: biwfa_device.hpp, AWV_LDS_CHAIN)
       kp.chain_max = narrow ? chain_max : (awv::TMAX32 == awv::TMAX ? std::min(chain_max, 3) : 1);

@@ -380,7 +380,8 @@ def test_packed_probes_of_unstaged_sub_problems(oracle):
     150 kbp pair is still unstaged), a sequence's very first and last bases (the first sequence of the set: the pad words in
     front of the packed array), reverse-complemented queries, one wave per pair (a 6 KB staging region: 20 kbp pairs are
     unstaged there) and four, 16- and 32-bit rows -- against the oracle and against the raw-byte probes (AWV_F_NO_PACKED_SEQ).
-    A pair with a non-ACGT base keeps the raw bytes."""
+    A pair with a non-ACGT base keeps the raw bytes.  The 150 kbp pair is also the case of a launch with 32-bit rows whose
+    sub-problems below 32,760 bases are searched with 16-bit rows (AWV_SUB16); AWV_F_FORCE_INT32 pins 32-bit rows throughout."""
     from allwave_amd import ffi
     rng = random.Random(777)
     comp = {65: 84, 84: 65, 67: 71, 71: 67}
@@ -404,7 +405,8 @@ def test_packed_probes_of_unstaged_sub_problems(oracle):
     for p in long_pairs + short_pairs:
         want[p] = al.align(plain.get(p[0], seqs[p[0]]), seqs[p[1]])
     for flags, pairs in ((0, long_pairs + short_pairs), (ffi.AWV_F_ONE_WAVE, short_pairs), (ffi.AWV_F_ONE_WAVE | ffi.AWV_F_FORCE_INT32, short_pairs),
-                         (ffi.AWV_F_FOUR_WAVES | ffi.AWV_F_NO_PACKED_SEQ, long_pairs[:1] + short_pairs)):
+                         (ffi.AWV_F_FOUR_WAVES | ffi.AWV_F_NO_PACKED_SEQ, long_pairs[:1] + short_pairs),
+                         (ffi.AWV_F_FORCE_INT32, long_pairs[:1])):  # (32-bit rows throughout: no 16-bit searches of the short sub-problems)
         e = ffi.Engine(flags=flags)
         try:
             e.set_sequences(seqs)
