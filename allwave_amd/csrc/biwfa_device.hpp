@@ -2657,11 +2657,13 @@ __device__ __forceinline__ void emit_run(Emit& em, uint8_t op, int len) {
 template <typename OffT>
 __device__ __forceinline__ int bt_fetch(const KParams& kp, const RowMeta* base_meta, const OffT* hist, int kmin,
                                         int max_score, int comp, int score, int k, int add, int type) {
-  if (score < 0 || score > max_score) return -1;
-  const RowMeta m = base_meta[score * NCOMP + comp];
-  if (k < m.lo || k > m.hi) return -1;
-  int32_t v = (int32_t)hist[((size_t)score * NCOMP + comp) * (size_t)kp.wb_cap + (k - kmin)];
-  if (v < 0) return -1;
+  // the row's metadata and the value are fetched together -- one memory round trip per backtrace step instead of two in series
+  // (a score or diagonal outside what exists reads a valid dummy position and is rejected afterwards)
+  const bool sok = score >= 0 && score <= max_score;
+  const int sr = sok ? score : 0;
+  const RowMeta m = base_meta[sr * NCOMP + comp];
+  int32_t v = (int32_t)hist[((size_t)sr * NCOMP + comp) * (size_t)kp.wb_cap + (size_t)min(max(k - kmin, 0), kp.wb_cap - 1)];
+  if (!sok || k < m.lo || k > m.hi || v < 0) return -1;
   if (wenc_of<OffT>()) v += max(k, 0);  // stored form -> text offset
   return ((v + add) << 4) | type;
 }
@@ -2825,9 +2827,12 @@ __device__ __forceinline__ int base_align(const KParams& kp, Shared& sh, const L
         if (lane == 0) cand = bt_fetch(kp, base_meta, hist, kmin, score, C_D2, gap_extend2, k + 1, 0, BT_D2_EXT);
         if (lane == 1) cand = bt_fetch(kp, base_meta, hist, kmin, score, C_M, gap_open2, k + 1, 0, BT_D2_OPEN);
       }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) cand = max(cand, __shfl_xor(cand, o));
-      const int max_all = __shfl(cand, 0);
+      // max over lanes 0..15 on the DPP network (row_shr 1, 2, 4, 8 leave it in lane 15; lanes 9.. hold -1)
+      cand = max(cand, __builtin_amdgcn_update_dpp(-1, cand, 0x111, 0xf, 0xf, false));
+      cand = max(cand, __builtin_amdgcn_update_dpp(-1, cand, 0x112, 0xf, 0xf, false));
+      cand = max(cand, __builtin_amdgcn_update_dpp(-1, cand, 0x114, 0xf, 0xf, false));
+      cand = max(cand, __builtin_amdgcn_update_dpp(-1, cand, 0x118, 0xf, 0xf, false));
+      const int max_all = __builtin_amdgcn_readlane(cand, 15);
       if (max_all < 0) { err = ST_INTERNAL; break; }
       if (matrix == C_M) {
         const int max_offset = max_all >> 4;
