@@ -84,10 +84,11 @@ typedef struct {
                                    wider rows (fail fast; with first_row_cols: the way to see a failed pair's record end to end) */
 /* ---- variant pins: tests and A/B measurements only.  Results are identical under every one of them (tests/test_gpu_parity.py
  * runs the pairs of variants against each other and against the oracle); a product caller leaves them alone. */
-#define AWV_F_FORCE_INT32 2    /* always use 32-bit wavefront rows (default: 16-bit when lengths < 32760, and -- in the
-                                  four- and sixteen-wave flavours -- when only the shorter length is: rows of min(h, v)) */
+#define AWV_F_FORCE_INT32 2    /* always use 32-bit wavefront rows, for every sub-problem (default: 16-bit when lengths < 32760,
+                                  and -- in the four- and sixteen-wave flavours -- when only the shorter length is: rows of
+                                  min(h, v); a launch with 32-bit rows searches the sub-problems that fit with 16-bit rows) */
 #define AWV_F_NO_WIDE16 256    /* 32-bit rows whenever the longer sequence has 32760 bases or more (no min(h, v) rows) */
-#define AWV_F_NO_PACKED_SEQ 4  /* never stage 2-bit packed sequences in LDS (raw-byte probes from HBM only) */
+#define AWV_F_NO_PACKED_SEQ 4  /* never use the 2-bit packed sequences, staged in LDS or in place (raw-byte probes from HBM only) */
 #define AWV_F_ONE_WAVE 8       /* always one wave per pair (default: four waves per pair for small batches, long sequences and unequal lengths, sixteen for a few very unequal pairs) */
 #define AWV_F_FOUR_WAVES 16    /* always four waves per pair */
 #define AWV_F_NO_CHAIN 128     /* multi-step passes of one sweep only (no chaining of sweeps through registers / LDS) */
