@@ -21,7 +21,9 @@
 //     passes of 5 scores that also store every I/D row (deep_phase), until phase 1 of the search ends; phase 2
 //     and trimmed rows go score by score (compute_row), forward and reverse steps fused, one barrier per step;
 //   * long sequences (32-bit rows): three chained sweeps with the middle sweep's rows in LDS wherever the
-//     sub-problem is too long for its packed sequences to be staged there;
+//     sub-problem is too long for its packed sequences to be staged there; such a sub-problem probes the 2-bit
+//     words where they lie in HBM (seq_mode 2), and every sub-problem that has become short enough is searched
+//     with 16-bit rows inside the same launch (AWV_SUB16);
 //   * the far-apart phase (multi_phase, which tail-calls deep_phase), the base case's passes (base_phase), the
 //     breakpoint search (find_breakpoint_fn) and the trimmed-hull search (trim_pass_fn) are real functions with
 //     register files of their own; their inputs travel through LDS (Shared::pctx); the passes' planning
@@ -532,6 +534,15 @@ __device__ __forceinline__ int packed_first_count(const uint32_t* seq, const Sub
 #ifndef AWV_PROBE_BATCH
 #define AWV_PROBE_BATCH 2  // cells per batch of LDS reads: 0 = the compiler's own order, 2, 4 (config 2, same box: 1645 / 1629 / 1660 ms)
 #endif
+// experiment (off): wave priority raised while a window issues its row loads (1) and also while a step issues its probe reads (2)
+#ifndef AWV_SETPRIO
+#define AWV_SETPRIO 0
+#endif
+#if AWV_SETPRIO
+#define AWV_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define AWV_PRIO(n) ((void)0)
+#endif
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 template <int DIR, int NB>
 __device__ __forceinline__ void packed_first_counts4(const uint32_t* seq, const SubCtx& cx, const int (&vv)[4], const int (&hh)[4], int (&nn)[4]) {
@@ -1004,6 +1015,7 @@ __device__ __forceinline__ void extend_cells_lean(const Lds<OffT>& lds, const Su
   for (int j = 0; j < 4; ++j) rr[j] = hmaxv[j] - cand[j];
   if (cx.seq_mode == 1) {
     positions(AWV_OOB_PROBES != 0);
+    if (AWV_SETPRIO >= 2) AWV_PRIO(2);
     if constexpr (NBATCH != 0) {
       if (dir == 0) packed_first_counts4<0, NBATCH ? NBATCH : 4>(seq, cx, vv, hh, nn);
       else packed_first_counts4<1, NBATCH ? NBATCH : 4>(seq, cx, vv, hh, nn);
@@ -1014,6 +1026,7 @@ __device__ __forceinline__ void extend_cells_lean(const Lds<OffT>& lds, const Su
 #pragma unroll
       for (int j = 0; j < 4; ++j) nn[j] = packed_first_count<1>(seq, cx, vv[j], hh[j]);
     }
+    if (AWV_SETPRIO >= 2) AWV_PRIO(0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int t = min(nn[j], rr[j]);
@@ -1662,6 +1675,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
       for (int r = 0; r < NW; ++r) v.w[r] = keep ? v.w[r] : nullw;
     };
     const unsigned long long tm0 = PROF_NOW();
+    AWV_PRIO(3);
     // ---- the I/D rows the pass begins with
     V qI1[E1], qD1[E1], qI2[E2], qD2[E2];
 #pragma unroll
@@ -1730,6 +1744,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
       const int sb = s0 + h * TM;   // this sweep covers scores sb + 1 .. sb + TM
       const int tb = h * TM;        // its first step index within the pass
       const int tn = min(TM, Tn - tb);
+      AWV_PRIO(3);
       const bool own0 = CHAIN && h >= 1, own1 = CHAIN && (ALIAS || lds_chain ? h >= 1 : (CH >= 3 && h >= 2));  // (uniform) M sources 0 / 1 come from registers (or, 32-bit rows, from LDS)
       // ---- 16-bit rows: all row loads of the sweep, back to back (one memory round trip per sweep).  32-bit rows (a lane
       // vector is four registers; TM x NT of them do not fit): the M sources of a step are loaded one step ahead -- `cur`
@@ -1777,6 +1792,7 @@ __device__ __forceinline__ int compute_rows_multi(const KParams& kp, Shared& sh,
           }
         }
       }
+      AWV_PRIO(0);
       if (!interior) {
         if (h == 0) {
 #pragma unroll
